@@ -1,0 +1,176 @@
+/*
+ * xvec_hip.h -- C ABI of libxvec_hip.so: the MI355X (gfx950) x-vector forward path.
+ *
+ * This is the drop-in boundary for the ONE hot path this repository accelerates: the
+ * predict sub-graph the reference runs inside TensorFlow,
+ *
+ *     model/trainer.py:886-913   Trainer.predict  -> sess.run(self.embeddings, ...)
+ *     model/trainer.py:325-338   Trainer.build("predict") / :379-383 predict_setup
+ *     model/tdnn.py:36-181       tdnn()           (frame layers, pooling, segment layers)
+ *     model/pooling.py:8-240     general_pooling / statistics_pooling / self_attention
+ *     model/trainer.py:385-405   entire_network   (endpoints["output"], l2_scaling)
+ *
+ * The reference has no FFI for this path (TensorFlow *is* its backend), so the entry
+ * points below are what a binding for it would need -- each cites the reference call it
+ * stands in for.  Plain C types only: pointers, sizes, int codes.  All device pointers
+ * are caller-owned (the Python host hands in torch tensors' data_ptr()); the library
+ * owns only the packed weights (handle) and the batch-geometry index arrays (plan).
+ *
+ * Every function returns XV_OK (0) or a negative xv_status; it never throws or aborts.
+ * The message for the last failure on a handle is xv_last_error(handle); for failures
+ * with no handle (xv_create) pass NULL.
+ *
+ * Threading: a handle may be shared by threads for xv_plan_* calls; concurrent
+ * xv_forward calls on one handle need distinct workspaces and distinct streams.
+ * xv_forward only enqueues work on `stream` and returns (no host synchronisation, no
+ * allocation: it may be captured into a hipGraph).
+ */
+#ifndef XVEC_HIP_H_
+#define XVEC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xv_handle xv_handle;   /* one model resident on one device */
+typedef struct xv_plan xv_plan;       /* one batch geometry (frame offsets) + output node */
+
+typedef enum {
+  XV_OK = 0,
+  XV_ERR_INVALID = -1,        /* bad argument / shape mismatch / unknown name        */
+  XV_ERR_UNSUPPORTED = -2,    /* network_type / pooling_type not implemented         */
+  XV_ERR_MISSING_TENSOR = -3, /* xv_finalize: a variable of the graph was never set   */
+  XV_ERR_HIP = -4,            /* a HIP runtime call failed                           */
+  XV_ERR_STATE = -5,          /* call order violated (e.g. forward before finalize)  */
+  XV_ERR_WORKSPACE = -6,      /* workspace / output buffer too small                 */
+  XV_ERR_TOO_SHORT = -7       /* an utterance has fewer frames than the node needs   */
+} xv_status;
+
+/* network_type: model/trainer.py:100-110 (only "tdnn" is on the hot path this round) */
+enum { XV_NET_TDNN = 0 };
+/* pooling_type: model/pooling.py:14-23 */
+enum { XV_POOL_STATISTICS = 0, XV_POOL_SELF_ATTENTION = 1 };
+/* network_relu_type: model/tdnn.py:28-33 */
+enum { XV_ACT_RELU = 0, XV_ACT_LRELU = 1, XV_ACT_PRELU = 2 };
+/* arithmetic of the matrix products */
+enum {
+  XV_PREC_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate   */
+  XV_PREC_BF16X3 = 1   /* 3x v_mfma_f32_32x32x16_bf16 on hi/lo bf16 splits, fp32 accumulate
+                          (~1e-5 relative; meets the 1e-4 parity bar at 5x the MFMA rate) */
+};
+
+#define XV_MAX_ATT_LAYERS 4
+
+/* Graph description: the hyper-parameters of nnet/config.json that shape the predict
+ * graph (model/tdnn.py:28-33,114-116,152-154,163-164,173-174; model/pooling.py:72-88;
+ * model/trainer.py:400-403). */
+typedef struct {
+  int32_t struct_size;              /* = sizeof(xv_model_desc), for ABI checking           */
+  int32_t network_type;             /* XV_NET_*                                            */
+  int32_t feat_dim;                 /* nnet/feature_dim (extract.py:54-55)                 */
+  int32_t channels;                 /* 512 in the reference (model/tdnn.py:43); tests shrink */
+  int32_t pooling_type;             /* XV_POOL_*                                           */
+  int32_t relu_type;                /* XV_ACT_*                                            */
+  int32_t num_nodes_pooling_layer;  /* default 1500                                        */
+  int32_t num_nodes_last_layer;     /* default 512                                         */
+  int32_t last_layer_no_bn;
+  int32_t last_layer_linear;
+  int32_t feature_norm;             /* endpoints["output"] = l2_scaling(output)            */
+  float feature_scaling_factor;
+  /* self-attention (model/pooling.py:55-240) */
+  int32_t att_key_input;            /* 3/4/5: endpoints["tdnn<N>_relu"]                    */
+  int32_t att_value_input;
+  int32_t att_num_key_layers;       /* len(att_key_num_nodes), 1..XV_MAX_ATT_LAYERS        */
+  int32_t att_key_num_nodes[XV_MAX_ATT_LAYERS];
+  int32_t att_key_network_type;     /* 0 affine, 1 +relu, 2 +bn+relu, 3 +tanh             */
+  int32_t att_num_value_layers;     /* len(att_value_num_nodes), 0..XV_MAX_ATT_LAYERS      */
+  int32_t att_value_num_nodes[XV_MAX_ATT_LAYERS];
+  int32_t att_value_network_type;
+  int32_t att_apply_nonlinear;
+  int32_t att_use_scale;
+  int32_t att_num_heads;
+  int32_t att_split_value;
+  int32_t att_split_key;
+  int32_t precision;                /* XV_PREC_*                                           */
+} xv_model_desc;
+
+typedef struct {
+  int32_t struct_size;
+  int32_t node_id;
+  int32_t batch;            /* B                                                           */
+  int32_t frame_level;      /* 1: output is packed frames [out_rows, out_cols]; 0: [B, out_cols] */
+  int64_t in_frames;        /* total input frames (frame_offsets[B])                       */
+  int64_t out_rows;         /* rows of the output matrix                                   */
+  int64_t out_cols;         /* width E of the chosen node                                  */
+  int64_t workspace_bytes;  /* device scratch xv_forward needs (256-byte aligned base)     */
+  int64_t flops;            /* algorithmic 2*M*N*K of the contractions this plan runs      */
+} xv_plan_info;
+
+/* Library / build identification ("xvec_hip <version> gfx950"). */
+const char* xv_version(void);
+
+/* Trainer.__init__ + build("predict") (model/trainer.py:87-219, 325-338): create the
+ * predict graph for `desc` on HIP device `device`.  No weights yet. */
+int xv_create(const xv_model_desc* desc, int device, xv_handle** out);
+
+/* Saver.restore of one variable (model/trainer.py:277-295).  `tf_name` is the TensorFlow
+ * variable name ("tdnn/tdnn1_conv/kernel", "tdnn/tdnn1_bn/moving_mean",
+ * "tdnn/attention/query", ...); `host` is fp32, C-contiguous, in the variable's own
+ * layout (conv kernels HWIO [1,k,cin,cout], dense kernels [in,out]). */
+int xv_set_tensor(xv_handle* h, const char* tf_name, const float* host, const int64_t* shape, int rank);
+
+/* End of restore: checks that every variable of the graph is present, derives the
+ * per-channel BN scale/shift, packs the kernels into the MFMA tile layout and uploads. */
+int xv_finalize(xv_handle* h);
+
+/* endpoints[...] key -> node id (model/trainer.py:380 `endpoints[params.embedding_node]`).
+ * Returns the id (>= 0) or XV_ERR_INVALID for a name the graph does not define. */
+int xv_node_id(const xv_handle* h, const char* endpoint_name);
+
+/* Number of frames of temporal context the node consumes (14 for everything at or past
+ * tdnn3); an utterance needs more than this many frames. */
+int xv_node_context(const xv_handle* h, int node_id);
+
+/* Batch geometry.  `frame_offsets` (host, B+1 ascending int32, [0] == 0) delimits the B
+ * utterances inside the packed feature matrix.  Builds the device-side row maps once, so
+ * xv_forward for this geometry is launch-only.  The calls it makes on `stream` are
+ * complete when xv_plan_create returns. */
+int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int node_id, void* stream,
+                   xv_plan** out);
+int xv_plan_query(const xv_plan* p, xv_plan_info* info);
+void xv_plan_destroy(xv_plan* p);
+
+/* sess.run(self.embeddings, {features, is_training: False}) (model/trainer.py:909).
+ *   feats_dev : device fp32, packed frames [in_frames, feat_ld]; the first feat_dim columns
+ *               are used (trainer.py:906-907 drops extra columns), feat_ld >= feat_dim.
+ *   out_dev   : device fp32 [out_rows, out_cols], row-major, out_capacity = element count.
+ *   workspace : device scratch >= workspace_bytes, 256-byte aligned.
+ *   stream    : hipStream_t (torch.cuda.current_stream().cuda_stream), NULL = default. */
+int xv_forward(xv_handle* h, const xv_plan* p, const float* feats_dev, int feat_ld, float* out_dev,
+               int64_t out_capacity, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Per-kernel timing of one xv_forward, measured with hipEvents on `stream` (synchronises;
+ * for bench.py / profiling only).  Writes up to `max_entries` records and returns the count
+ * (>= 0) or a negative xv_status.  flops/bytes are the ALGORITHMIC figures of the launch. */
+typedef struct {
+  char name[48];
+  float ms;
+  int64_t flops;
+  int64_t bytes;
+} xv_kernel_time;
+int xv_forward_timed(xv_handle* h, const xv_plan* p, const float* feats_dev, int feat_ld, float* out_dev,
+                     int64_t out_capacity, void* workspace, int64_t workspace_bytes, void* stream,
+                     xv_kernel_time* entries, int max_entries);
+
+/* Trainer.close (model/trainer.py:270-275). */
+void xv_destroy(xv_handle* h);
+
+const char* xv_last_error(const xv_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XVEC_HIP_H_ */

@@ -1,0 +1,195 @@
+"""ORACLE (test infrastructure, never shipped, never on the product path).
+
+Independent fp32 torch-CPU restatement of the reference forward path, written against
+torch.nn.functional (conv1d / linear) instead of the shifted-matmul form used by
+oracle/ref_numpy.py, so that the two restatements cross-check each other
+(tests/test_oracle.py requires <=1e-6 relative L2 between them).  It is also the
+`cpu_baseline` of bench.py (kind "port"): one compute thread, one utterance per call,
+mirroring model/trainer.py:135-139 (intra=inter=1) and
+egs/voxceleb/v1/nnet/lib/extract.py:89 (batch of one).
+
+**parity unpinned** for the TDNN layers (see oracle/ref_numpy.py header).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPSILON = 1e-3
+LRELU_ALPHA = 0.2
+VAR2STD_EPSILON = 1e-12
+
+
+def _get(params, key, default=None):
+    if isinstance(params, dict):
+        return params.get(key, default)
+    d = getattr(params, "dict", None)
+    if d is None:
+        d = params.__dict__
+    return d.get(key, default)
+
+
+class TorchTdnn(object):
+    """Weights converted once (like a restored TF session), then `forward` per call."""
+
+    def __init__(self, weights, params, dtype=torch.float32):
+        self.params = params
+        self.dtype = dtype
+        self.w = {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v))).to(dtype) for k, v in weights.items()}
+        # conv kernels [1,k,cin,cout] (HWIO) -> conv1d weight [cout,cin,k]   (model/tdnn.py:42-47)
+        self.conv = {}
+        for i in (1, 2, 3):
+            k = self.w["tdnn/tdnn%d_conv/kernel" % i]
+            self.conv[i] = k[0].permute(2, 1, 0).contiguous()
+
+    def _bn(self, x, scope):
+        w = self.w
+        return w[scope + "/gamma"] * (x - w[scope + "/moving_mean"]) / torch.sqrt(
+            w[scope + "/moving_variance"] + BN_EPSILON) + w[scope + "/beta"]
+
+    def _act(self, x, scope):
+        t = _get(self.params, "network_relu_type")
+        if t == "prelu":                                   # model/common.py:27-42
+            return F.relu(x) + self.w[scope + "/alpha"] * (x - x.abs()) * 0.5
+        if t == "lrelu":
+            return F.leaky_relu(x, LRELU_ALPHA)
+        return F.relu(x)
+
+    def _dense_block(self, x, name, kind, ep, scope="tdnn/attention"):
+        base = "%s/%s" % (scope, name)
+        x = F.linear(x, self.w["%s/%s_dense/kernel" % (base, name)].t(), self.w["%s/%s_dense/bias" % (base, name)])
+        ep["%s_dense" % name] = x
+        if kind == 2:
+            x = self._bn(x, "%s/%s_bn" % (base, name))
+            ep["%s_bn" % name] = x
+        if kind in (1, 2):
+            x = self._act(x, "%s/%s_relu" % (base, name))
+            ep["%s_relu" % name] = x
+        if kind == 3:
+            x = torch.tanh(x)
+            ep["%s_tanh" % name] = x
+        return x
+
+    def _stat_pool(self, x):                               # model/pooling.py:27-52
+        mean = x.mean(dim=1, keepdim=True)
+        var = ((x - mean) ** 2).mean(dim=1)
+        var = torch.where(var <= VAR2STD_EPSILON, torch.full_like(var, VAR2STD_EPSILON), var)
+        return torch.cat([mean[:, 0], var.sqrt()], dim=1)
+
+    def _attention(self, ep):                              # model/pooling.py:55-240
+        p = self.params
+        value = ep[_get(p, "att_value_input")]
+        key = ep[_get(p, "att_key_input")]
+        kn = list(_get(p, "att_key_num_nodes"))
+        for i in range(len(kn) - 1):
+            key = self._dense_block(key, "att_key%d" % i, 2, ep)
+        key = self._dense_block(key, "att_key%d" % (len(kn) - 1), int(_get(p, "att_key_network_type")), ep)
+        vn = list(_get(p, "att_value_num_nodes"))
+        if vn:
+            for i in range(len(vn) - 1):
+                value = self._dense_block(value, "att_value%d" % i, 2, ep)
+            value = self._dense_block(value, "att_value%d" % (len(vn) - 1), int(_get(p, "att_value_network_type")), ep)
+        h = int(_get(p, "att_num_heads"))
+        q = self.w["tdnn/attention/query"]
+        b, l, dv = value.shape
+        dk = key.shape[-1]
+        if _get(p, "att_split_key"):
+            k4 = key.reshape(b, l, h, dk // h).permute(0, 2, 1, 3)
+            qk = (k4 * q[None, :, None, :]).sum(-1)                     # [b,h,l]
+            dkh = dk // h
+        else:
+            qk = torch.einsum('bld,hd->bhl', key, q)
+            dkh = dk
+        if _get(p, "att_use_scale"):
+            qk = qk * (1.0 / np.sqrt(float(dkh)))
+        w = torch.softmax(qk, dim=-1)
+        ep["attention_weights"] = w
+        if _get(p, "att_split_value"):
+            v4 = value.reshape(b, l, h, dv // h).permute(0, 2, 1, 3)    # [b,h,l,d]
+        else:
+            v4 = value[:, None].expand(b, h, l, dv)
+        mean = (v4 * w[..., None]).sum(2)
+        var = (((v4 - mean[:, :, None, :]) ** 2) * w[..., None]).sum(2)
+        mean = mean.reshape(b, -1)
+        var = var.reshape(b, -1)
+        var = torch.where(var <= VAR2STD_EPSILON, torch.full_like(var, VAR2STD_EPSILON), var)
+        att = torch.cat([mean, var.sqrt()], dim=1)
+        ep["att_output_before_nonlinear"] = att
+        if _get(p, "att_apply_nonlinear"):
+            att = self._bn(att, "tdnn/attention/att_post_bn")
+            ep["att_post_bn"] = att
+            att = self._act(att, "tdnn/attention/att_post_relu")
+            ep["att_post_relu"] = att
+        return att
+
+    @torch.no_grad()
+    def forward(self, features):
+        """features: [b,l,d] -> endpoints (OrderedDict of torch tensors)."""
+        p = self.params
+        ep = OrderedDict()
+        x = torch.as_tensor(np.ascontiguousarray(features)).to(self.dtype)
+        x = x.transpose(1, 2)                              # [b,d,l] for conv1d
+        for i in (1, 2, 3):                                # model/tdnn.py:40-96
+            s = "tdnn/tdnn%d" % i
+            if x.shape[2] < self.conv[i].shape[2]:
+                x = x.new_zeros((x.shape[0], self.conv[i].shape[0], 0))
+            else:
+                x = F.conv1d(x, self.conv[i], self.w[s + "_conv/bias"])
+            y = x.transpose(1, 2)
+            ep["tdnn%d_conv" % i] = y
+            y = self._bn(y, s + "_bn")
+            ep["tdnn%d_bn" % i] = y
+            y = self._act(y, s + "_relu")
+            ep["tdnn%d_relu" % i] = y
+            x = y.transpose(1, 2)
+        x = x.transpose(1, 2)
+        for i in (4, 5):                                   # model/tdnn.py:99-130
+            s = "tdnn/tdnn%d" % i
+            x = F.linear(x, self.w[s + "_dense/kernel"].t(), self.w[s + "_dense/bias"])
+            ep["tdnn%d_dense" % i] = x
+            x = self._bn(x, s + "_bn")
+            ep["tdnn%d_bn" % i] = x
+            x = self._act(x, s + "_relu")
+            ep["tdnn%d_relu" % i] = x
+        ptype = _get(p, "pooling_type")                    # model/pooling.py:8-25
+        if ptype == "statistics_pooling":
+            x = self._stat_pool(x)
+        elif ptype == "self_attention":
+            x = self._attention(ep)
+        else:
+            raise NotImplementedError("Not implement %s pooling" % ptype)
+        ep["pooling"] = x
+        x = F.linear(x, self.w["tdnn/tdnn6_dense/kernel"].t(), self.w["tdnn/tdnn6_dense/bias"])
+        ep["tdnn6_dense"] = x
+        x = self._bn(x, "tdnn/tdnn6_bn")
+        ep["tdnn6_bn"] = x
+        x = self._act(x, "tdnn/tdnn6_relu")
+        ep["tdnn6_relu"] = x
+        x = F.linear(x, self.w["tdnn/tdnn7_dense/kernel"].t(), self.w["tdnn/tdnn7_dense/bias"])
+        ep["tdnn7_dense"] = x
+        if not _get(p, "last_layer_no_bn", False):
+            x = self._bn(x, "tdnn/tdnn7_bn")
+            ep["tdnn7_bn"] = x
+        if not _get(p, "last_layer_linear", False):
+            x = self._act(x, "tdnn/tdnn7_relu")
+            ep["tdnn7_relu"] = x
+        ep["output"] = x
+        if _get(p, "feature_norm", False):                 # model/trainer.py:400-403
+            sq = (x * x).sum(-1, keepdim=True)
+            ep["output"] = x * (float(_get(p, "feature_scaling_factor")) * torch.rsqrt(torch.clamp(sq, min=1e-12)))
+        return ep
+
+    def predict(self, features, dim, node=None):
+        """model/trainer.py:886-913."""
+        features = np.asarray(features)
+        rank = features.ndim
+        assert rank in (2, 3)
+        if rank == 2:
+            features = features[None]
+        if features.shape[-1] != dim:
+            features = features[:, :, :dim]
+        ep = self.forward(features)
+        e = ep[node if node else _get(self.params, "embedding_node")].numpy()
+        return e[0] if rank == 2 else e

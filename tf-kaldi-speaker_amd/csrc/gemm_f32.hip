@@ -1,0 +1,193 @@
+// fp32 MFMA GEMM for gfx950 (MI355X): temporal convolution / dense layers of the TDNN as an
+// "overlapping-row" GEMM with a fused bias + batch-norm + activation epilogue.
+//
+//   Y[rowmap[m], n] = act((sum_k A[m,k] * Wt[n,k]) * scale[n] + shift[n]),  A[m,k] = X[m*ldx + k]
+//
+// replaces tf.layers.conv2d (1,w) / tf.layers.dense + tf.layers.batch_normalization + relu
+// (model/tdnn.py:42-130,137-179) with one launch per layer.
+//
+// Design (CDNA4):
+//  * v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (bitwise an fmaf chain), 64
+//    FLOP/clk/SIMD -> 157 TFLOP/s chip peak.  A wave owns a 64x64 output tile = 2x2 MFMA tiles
+//    (64 accumulator VGPRs); a 256-thread workgroup owns 128x128; two workgroups per CU.
+//  * The K index of an MFMA is only a summation label, so both operands use the same permuted k
+//    order: lane (r, h) reads FOUR consecutive k (one ds_read_b128) and feeds them to four
+//    successive MFMAs (k = 8q + 4h + j).  One b128 LDS read per operand per 4 MFMAs.
+//  * LDS tiles are [row][32 + 4 pad] floats: the 144-byte row stride makes every ds_read_b128
+//    lane group hit 16 distinct 16-byte slots (conflict free) and keeps ds_write_b128 aligned.
+//  * Register-staged double buffering: the global loads of tile t+1 are issued before the
+//    MFMAs of tile t and written to the other LDS buffer after them; one barrier per K tile.
+//  * Weights are pre-packed [Npad][Kpad] (k contiguous, zero padded), so the B tile is loaded
+//    exactly like the A tile and needs no bounds checks.
+//  * XCD-aware block order: consecutive ids on one XCD (id % 8) walk the N tiles of the same M
+//    tile, so the A panel is fetched once per XCD L2.
+#include "xv_kernels.h"
+
+namespace xv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDT = BK + 4;               // padded LDS row (floats)
+constexpr int TILE_F = BM * LDT;          // floats per operand tile
+
+__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.0f);
+    case ACT_LRELU: return fmaxf(v, kLreluAlpha * v);                 // tf.nn.leaky_relu
+    case ACT_PRELU: return fmaxf(v, 0.0f) + alpha * (v - fabsf(v)) * 0.5f;  // model/common.py:40-42
+    case ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// XCD-aware bijective remap of a 1-D grid (cdna guide T1): ids congruent mod 8 share an XCD.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7, i = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, int nNt) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][BM][LDT]
+  float* Bs = smem + 2 * TILE_F;    // [2][BN][LDT]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+
+  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
+  const int mt = tile / nNt, nt = tile - mt * nNt;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // staging map: thread -> (row lr + 32*i, float4 column c4)
+  const int c4 = tid & 7, lr = tid >> 3;
+  const int nk = p.Kpad / BK;
+
+  f32x4 ra[4], rb[4];
+  auto load_tiles = [&](int kt) {
+    const int k = kt * BK + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = lr + 32 * i;
+      rb[i] = *reinterpret_cast<const f32x4*>(p.Wt + (int64_t)(n0 + row) * p.Kpad + k);
+      if (ALIGNED) {
+        if (k < p.K)
+          ra[i] = *reinterpret_cast<const f32x4*>(p.X + (int64_t)(m0 + row) * p.ldx + k);
+        else
+          ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        const int m = m0 + row;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < p.M) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kk = k + e;
+            if (kk < p.K) {
+              const int dr = kk / p.cin;
+              v[e] = p.X[(int64_t)(m + dr) * p.ldx + (kk - dr * p.cin)];
+            }
+          }
+        }
+        ra[i] = v;
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = lr + 32 * i;
+      *reinterpret_cast<f32x4*>(As + buf * TILE_F + row * LDT + c4 * 4) = ra[i];
+      *reinterpret_cast<f32x4*>(Bs + buf * TILE_F + row * LDT + c4 * 4) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  const float* a_base = As + (wm * 64 + r32) * LDT + 4 * h;
+  const float* b_base = Bs + (wn * 64 + r32) * LDT + 4 * h;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const float* ap = a_base + cur * TILE_F;
+    const float* bp = b_base + cur * TILE_F;
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + q * 8);
+      f32x4 a1 = *reinterpret_cast<const f32x4*>(ap + 32 * LDT + q * 8);
+      f32x4 b0 = *reinterpret_cast<const f32x4*>(bp + q * 8);
+      f32x4 b1 = *reinterpret_cast<const f32x4*>(bp + 32 * LDT + q * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj) {
+    const int n = n0 + wn * 64 + nj * 32 + r32;
+    const bool nok = n < p.N;
+    const float sc = nok ? p.scale[n] : 0.f;
+    const float sh = nok ? p.shift[n] : 0.f;
+    const float al = (nok && p.alpha) ? p.alpha[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < p.M && nok) {
+          const int orow = p.rowmap ? p.rowmap[m] : m;
+          if (orow >= 0) {
+            const float v = apply_act(fmaf(acc[mi][nj][e], sc, sh), p.act, al);
+            p.Y[(int64_t)orow * p.ldy + n] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s) {
+  if (a.M <= 0) return hipSuccess;
+  const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
+  const size_t smem = (size_t)4 * TILE_F * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid(nMt * nNt), block(256);
+  if (aligned)
+    hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, block, smem, s, a, nMt, nNt);
+  else
+    hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, block, smem, s, a, nMt, nNt);
+  return hipGetLastError();
+}
+
+}  // namespace xv

@@ -1,0 +1,91 @@
+// Internal launch interface between the C-ABI layer (xvec_api.hip) and the gfx950 kernels.
+// Host-side structs only; nothing here is exported from the shared library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xv {
+
+// Epilogue activation applied after  v = acc * scale[n] + shift[n].
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_PRELU = 3, ACT_TANH = 4 };
+
+constexpr float kLreluAlpha = 0.2f;       // tf.nn.leaky_relu default (model/tdnn.py:33)
+constexpr float kVarFloor = 1e-12f;       // VAR2STD_EPSILON (model/pooling.py:6)
+
+// One "overlapping-row" GEMM:  Y[rowmap[m], n] = act((sum_k A[m,k] * Wt[n,k]) * scale[n] + shift[n])
+//   A[m,k] = X[(m + k / cin) * ldx + k % cin]      (== X[m*ldx + k] when ldx == cin)
+// A dense layer has K == cin; a temporal convolution of width w has K == w*cin, so that row m
+// of A is the w consecutive input frames starting at frame m (model/tdnn.py:42-47).
+struct GemmArgs {
+  const float* X;         // activations, fp32
+  int64_t ldx;            // row stride of X in elements
+  int cin;                // channels per input frame
+  int M;                  // rows of A to compute (input rows minus w-1)
+  int K;                  // w * cin
+  int N;                  // output channels
+  const float* Wt;        // packed weights [Npad][Kpad], k contiguous, zero padded
+  int Kpad;               // multiple of 32
+  int Npad;               // multiple of 128
+  const float* scale;     // [N]
+  const float* shift;     // [N]
+  const float* alpha;     // [N] PReLU slopes (ACT_PRELU) or nullptr
+  int act;
+  const int32_t* rowmap;  // [M] output row or -1 (skip); nullptr = identity
+  float* Y;               // fp32 output (may be nullptr when only the split planes are wanted)
+  int64_t ldy;
+  // bf16x3 path: activations are carried between layers as two bf16 planes (hi + lo ~= fp32)
+  const uint16_t* Xhi;    // input planes (same indexing as X), nullptr on the fp32 path
+  const uint16_t* Xlo;
+  uint16_t* Yhi;          // output planes (same indexing as Y), nullptr when not needed
+  uint16_t* Ylo;
+  const uint16_t* Whi;    // packed weight planes [Npad][Kpad]
+  const uint16_t* Wlo;
+};
+
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) path.  aligned: ldx == cin (or K == cin), ldx % 4 == 0,
+// K % 4 == 0, X 16-byte aligned and followed by >= 160 rows of readable slack.
+hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s);
+
+// bf16x3 split path (3x v_mfma_f32_32x32x16_bf16 per product tile).
+hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s);
+// fp32 -> (hi, lo) bf16 planes, elementwise (used for the network input of the split path)
+hipError_t launch_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, hipStream_t s);
+
+// rowmap for a valid convolution of width w over packed utterances:
+//   in_off[b] = off0[b] - b*ctx_in  (rows of utterance b in the layer's input)
+//   row r of utterance b at local frame t maps to out_off[b] + t if t < len_b - (w-1), else -1.
+hipError_t launch_build_rowmap(const int32_t* off0, int B, int ctx_in, int w, int32_t* rowmap, int M,
+                               hipStream_t s);
+
+// statistics pooling (model/pooling.py:27-52):  out[b] = [mean_t x, sqrt(max-floor(var_t x))]
+//   rows of utterance b: [off0[b] - b*ctx, off0[b+1] - (b+1)*ctx)
+hipError_t launch_stat_pool(const float* x, int64_t ldx, int C, const int32_t* off0, int B, int ctx,
+                            float* out, int64_t ldo, hipStream_t s);
+
+// attention scores (model/pooling.py:189-194): score[r, h] = scale * sum_d key[r, h*dk_h + d] * q[h, d]
+// (split_key) or sum_d key[r, d] * q[h, d] (no split; dk_h == dk).
+hipError_t launch_att_scores(const float* key, int64_t ldk, int64_t rows, const float* query, int H,
+                             int dk_h, int split_key, float scale, float* scores, hipStream_t s);
+// softmax over time per (utterance, head), in place on scores [rows, H]; also writes the
+// [B, H, Lmax]-free packed layout weights_out[h * rows + r] when weights_out != nullptr.
+hipError_t launch_att_softmax(float* scores, int H, const int32_t* off0, int B, int ctx, hipStream_t s);
+// weighted mean / std (model/pooling.py:201-218).  value [rows, dv]; out[b] = [mean(h,d)..., std(h,d)...]
+hipError_t launch_att_pool(const float* value, int64_t ldv, int dv, const float* weights, int H,
+                           int split_value, const int32_t* off0, int B, int ctx, float* out, int64_t ldo,
+                           hipStream_t s);
+
+// y = act(x * scale[c] + shift[c]) on [rows, C] (att_post_bn / att_post_relu, stage replays)
+hipError_t launch_affine_act(const float* x, int64_t ldx, int64_t rows, int C, const float* scale,
+                             const float* shift, const float* alpha, int act, float* y, int64_t ldy,
+                             hipStream_t s);
+
+// l2_scaling (model/common.py:45-58): y = x * s * rsqrt(max(sum x^2, 1e-12)) per row
+hipError_t launch_l2_scale(const float* x, int64_t rows, int C, float factor, float* y, hipStream_t s);
+
+// transposed copy [B,H,L]-style attention weights: out[b][h][t] from scores [rows,H] (uniform L only)
+hipError_t launch_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int cols,
+                         hipStream_t s);
+hipError_t launch_att_weights_out(const float* scores, int H, const int32_t* off0, int B, int ctx,
+                                  float* out, hipStream_t s);
+
+}  // namespace xv

@@ -1,0 +1,894 @@
+// C ABI of libxvec_hip.so (include/xvec_hip.h): model handle, batch plan and the op executor
+// that strings the gfx950 kernels into the predict graph of the reference
+// (model/tdnn.py:36-181, model/pooling.py:8-240, model/trainer.py:385-405, 886-913).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/xvec_hip.h"
+#include "xv_kernels.h"
+
+using namespace xv;
+
+namespace {
+
+constexpr double kBnEps = 1e-3;        // tf.layers.batch_normalization default epsilon
+constexpr int kSlackRows = 160;        // readable rows after every activation buffer (GEMM tile overreach)
+constexpr int kAlign = 256;
+
+thread_local std::string g_last_error;  // failures with no handle (xv_create)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t alloc(size_t n) {
+    release();
+    bytes = n;
+    if (n == 0) return hipSuccess;
+    return hipMalloc(&p, n);
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+struct DeviceGuard {   // leave the caller's current device untouched
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+    if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+// ------------------------------------------------------------------------------ graph
+enum Stage : int { ST_AFFINE = 0, ST_BN = 1, ST_ACT = 2 };
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool set = false;
+};
+
+// An affine layer: temporal convolution (w > 1) or dense (w == 1), optional BN, optional activation.
+struct Layer {
+  std::string kernel_name, bias_name, bn_scope, alpha_name;
+  std::string ep[3];          // endpoint key per stage ("" when the stage does not exist)
+  int w = 1, cin = 0, cout = 0;
+  bool has_bn = false;
+  int act = ACT_NONE;         // activation of the final stage
+  // device
+  DevBuf wt;                  // fp32 [Npad][Kpad]
+  DevBuf whi, wlo;            // bf16 planes [Npad][Kpad] (bf16x3 path)
+  DevBuf vec;                 // [bias | bn_scale | bn_shift | alpha | ones] each cout floats
+  int Kpad = 0, Npad = 0;
+  int final_stage() const { return act != ACT_NONE ? ST_ACT : (has_bn ? ST_BN : ST_AFFINE); }
+  const float* d_bias() const { return static_cast<const float*>(vec.p); }
+  const float* d_scale() const { return d_bias() + cout; }
+  const float* d_shift() const { return d_bias() + 2 * cout; }
+  const float* d_alpha() const { return alpha_name.empty() ? nullptr : d_bias() + 3 * cout; }
+  const float* d_ones() const { return d_bias() + 4 * cout; }
+};
+
+enum OpKind : int {
+  OP_GEMM = 0,        // layer
+  OP_STAT_POOL,       // statistics pooling
+  OP_ATT_SCORES,      // key . query
+  OP_ATT_SOFTMAX,     // in place on the scores buffer (modelled as its own value)
+  OP_ATT_POOL,        // weighted mean/std
+  OP_AFFINE_ACT,      // att_post_bn / att_post_relu
+  OP_L2_SCALE         // endpoints["output"] with feature_norm
+};
+
+// A value is a matrix produced by an op (or the network input, value 0).
+struct Value {
+  bool frame_level = true;
+  int ctx = 0;        // temporal context consumed (frame-level values): rows = F0 - B*ctx
+  int cols = 0;
+};
+
+struct Op {
+  int kind = OP_GEMM;
+  int layer = -1;     // OP_GEMM
+  int in0 = -1, in1 = -1;   // value ids
+  int out = -1;       // value id
+  int bnvec = -1;     // OP_AFFINE_ACT: index into Model::post vectors
+};
+
+struct Node {         // an endpoints[...] key
+  std::string name;
+  int op = -1;        // producing op
+  int stage = -1;     // OP_GEMM: stage to emit; OP_AFFINE_ACT: 1 = bn only, 2 = bn + act
+  bool att_weights = false;
+};
+
+}  // namespace
+
+struct xv_handle {
+  xv_model_desc desc{};
+  int device = 0;
+  bool finalized = false;
+  std::string err;
+  std::mutex mu;
+  std::map<std::string, HostTensor> tensors;          // expected variables
+  std::vector<Layer> layers;
+  std::vector<Value> values;
+  std::vector<Op> ops;
+  std::vector<Node> nodes;
+  // attention extras
+  DevBuf query;                 // [H, dk_h]
+  int att_dk_h = 0, att_dk = 0, att_dv = 0;
+  std::string post_bn_scope, post_alpha_name;
+  DevBuf post_vec;              // [scale | shift | alpha] each pool_dim floats
+  int pool_dim = 0;
+};
+
+struct PlanStep {
+  int op = -1;
+  int stage = -1;               // stage override for the target op, else the op's final stage
+  bool to_out = false;          // writes the user's output buffer
+  int64_t out_off = -1;         // workspace byte offset of the output value
+  int64_t in0_off = -1, in1_off = -1;   // -2 = network input
+  int64_t rows_in = 0, rows_out = 0;
+  int M = 0;                    // GEMM rows to compute
+  int rowmap = -1;              // index into plan rowmaps (conv layers)
+  int64_t flops = 0, bytes = 0;
+};
+
+struct xv_plan {
+  xv_handle* h = nullptr;
+  xv_plan_info info{};
+  std::vector<int32_t> offsets;     // host copy
+  DevBuf d_offsets;                 // [B+1]
+  DevBuf d_rowmaps;                 // concatenated row maps
+  std::vector<int64_t> rowmap_off;  // element offsets into d_rowmaps
+  std::vector<PlanStep> steps;
+  bool uniform_len = true;
+  int uniform_L = 0;
+};
+
+namespace {
+
+int fail(xv_handle* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  g_last_error = buf;
+  return code;
+}
+
+#define XV_HIP(h, expr)                                                                              \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      return fail((h), XV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                  __LINE__);                                                                         \
+  } while (0)
+
+int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+uint16_t f32_to_bf16_rn(float f) {   // round to nearest even; inputs are finite weights
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float bf16_to_f32(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+void expect(xv_handle* h, const std::string& name, std::vector<int64_t> shape) {
+  HostTensor t;
+  t.shape = std::move(shape);
+  h->tensors[name] = std::move(t);
+}
+
+void expect_bn(xv_handle* h, const std::string& scope, int n) {
+  for (const char* s : {"gamma", "beta", "moving_mean", "moving_variance"}) expect(h, scope + "/" + s, {n});
+}
+
+int act_of(const xv_model_desc& d) {
+  return d.relu_type == XV_ACT_PRELU ? ACT_PRELU : (d.relu_type == XV_ACT_LRELU ? ACT_LRELU : ACT_RELU);
+}
+
+// adds layer + op + value + nodes; returns the output value id
+int add_layer(xv_handle* h, const std::string& var_scope, const std::string& ep_prefix, bool conv, int w,
+              int cin, int cout, bool has_bn, int act, int in_value, bool frame_level, int ctx_out,
+              const char* tanh_ep = nullptr) {
+  Layer L;
+  const std::string kind = conv ? "_conv" : "_dense";
+  L.kernel_name = var_scope + kind + "/kernel";
+  L.bias_name = var_scope + kind + "/bias";
+  L.w = w; L.cin = cin; L.cout = cout; L.has_bn = has_bn; L.act = act;
+  if (conv) expect(h, L.kernel_name, {1, w, cin, cout}); else expect(h, L.kernel_name, {cin, cout});
+  expect(h, L.bias_name, {cout});
+  L.ep[ST_AFFINE] = ep_prefix + kind;
+  if (has_bn) {
+    L.bn_scope = var_scope + "_bn";
+    expect_bn(h, L.bn_scope, cout);
+    L.ep[ST_BN] = ep_prefix + "_bn";
+  }
+  if (act != ACT_NONE) {
+    L.ep[ST_ACT] = ep_prefix + (act == ACT_TANH ? "_tanh" : "_relu");
+    if (act == ACT_PRELU) {
+      L.alpha_name = var_scope + "_relu/alpha";
+      expect(h, L.alpha_name, {cout});
+    }
+  }
+  (void)tanh_ep;
+  const int li = (int)h->layers.size();
+  h->layers.push_back(std::move(L));
+  Value v; v.frame_level = frame_level; v.ctx = ctx_out; v.cols = cout;
+  const int vid = (int)h->values.size();
+  h->values.push_back(v);
+  Op op; op.kind = OP_GEMM; op.layer = li; op.in0 = in_value; op.out = vid;
+  const int oi = (int)h->ops.size();
+  h->ops.push_back(op);
+  for (int s = 0; s < 3; ++s) {
+    const std::string& e = h->layers[li].ep[s];
+    if (!e.empty()) { Node n; n.name = e; n.op = oi; n.stage = s; h->nodes.push_back(n); }
+  }
+  return vid;
+}
+
+int add_simple_op(xv_handle* h, int kind, int in0, int in1, bool frame_level, int ctx, int cols) {
+  Value v; v.frame_level = frame_level; v.ctx = ctx; v.cols = cols;
+  const int vid = (int)h->values.size();
+  h->values.push_back(v);
+  Op op; op.kind = kind; op.in0 = in0; op.in1 = in1; op.out = vid;
+  h->ops.push_back(op);
+  return vid;
+}
+
+void add_node(xv_handle* h, const std::string& name, int op, int stage, bool attw = false) {
+  Node n; n.name = name; n.op = op; n.stage = stage; n.att_weights = attw;
+  h->nodes.push_back(n);
+}
+
+// Build the predict graph of model/tdnn.py:36-181 for `desc`.
+int build_graph(xv_handle* h) {
+  const xv_model_desc& d = h->desc;
+  const int C = d.channels, act = act_of(d);
+  h->values.clear();
+  Value in; in.frame_level = true; in.ctx = 0; in.cols = d.feat_dim;
+  h->values.push_back(in);   // value 0 = network input
+  int v = 0;
+  v = add_layer(h, "tdnn/tdnn1", "tdnn1", true, 5, d.feat_dim, C, true, act, v, true, 4);
+  v = add_layer(h, "tdnn/tdnn2", "tdnn2", true, 5, C, C, true, act, v, true, 8);
+  const int v3 = v = add_layer(h, "tdnn/tdnn3", "tdnn3", true, 7, C, C, true, act, v, true, 14);
+  const int v4 = v = add_layer(h, "tdnn/tdnn4", "tdnn4", false, 1, C, C, true, act, v, true, 14);
+  const int v5 = v = add_layer(h, "tdnn/tdnn5", "tdnn5", false, 1, C, d.num_nodes_pooling_layer, true, act, v, true, 14);
+
+  int pooled;
+  if (d.pooling_type == XV_POOL_STATISTICS) {
+    h->pool_dim = 2 * d.num_nodes_pooling_layer;
+    pooled = add_simple_op(h, OP_STAT_POOL, v5, -1, false, 0, h->pool_dim);
+    add_node(h, "pooling", (int)h->ops.size() - 1, -1);
+  } else if (d.pooling_type == XV_POOL_SELF_ATTENTION) {
+    auto pick = [&](int which) { return which == 3 ? v3 : (which == 4 ? v4 : (which == 5 ? v5 : -1)); };
+    int key = pick(d.att_key_input), val = pick(d.att_value_input);
+    if (key < 0 || val < 0)
+      return fail(h, XV_ERR_UNSUPPORTED, "att_key_input/att_value_input must be tdnn3_relu, tdnn4_relu or tdnn5_relu");
+    if (d.att_num_key_layers < 1 || d.att_num_key_layers > XV_MAX_ATT_LAYERS || d.att_num_value_layers < 0 ||
+        d.att_num_value_layers > XV_MAX_ATT_LAYERS)
+      return fail(h, XV_ERR_INVALID, "attention: bad number of key/value layers");
+    auto kind_to = [&](int kind, bool& bn, int& a) {
+      bn = kind == 2;
+      a = (kind == 1 || kind == 2) ? act : (kind == 3 ? ACT_TANH : ACT_NONE);
+    };
+    const std::string base = "tdnn/attention/";
+    for (int i = 0; i < d.att_num_key_layers; ++i) {                       // model/pooling.py:100-116
+      bool bn; int a;
+      kind_to(i < d.att_num_key_layers - 1 ? 2 : d.att_key_network_type, bn, a);
+      char nm[32]; snprintf(nm, sizeof(nm), "att_key%d", i);
+      key = add_layer(h, base + nm + "/" + nm, nm, false, 1, h->values[key].cols, d.att_key_num_nodes[i], bn, a, key, true, 14);
+    }
+    for (int i = 0; i < d.att_num_value_layers; ++i) {                     // model/pooling.py:119-135
+      bool bn; int a;
+      kind_to(i < d.att_num_value_layers - 1 ? 2 : d.att_value_network_type, bn, a);
+      char nm[32]; snprintf(nm, sizeof(nm), "att_value%d", i);
+      val = add_layer(h, base + nm + "/" + nm, nm, false, 1, h->values[val].cols, d.att_value_num_nodes[i], bn, a, val, true, 14);
+    }
+    const int H = d.att_num_heads;
+    h->att_dk = h->values[key].cols;
+    h->att_dv = h->values[val].cols;
+    if (H < 1) return fail(h, XV_ERR_INVALID, "att_num_heads must be >= 1");
+    if (d.att_split_key && h->att_dk % H) return fail(h, XV_ERR_INVALID, "key dim %d not divisible by %d heads", h->att_dk, H);
+    if (d.att_split_value && h->att_dv % H) return fail(h, XV_ERR_INVALID, "value dim %d not divisible by %d heads", h->att_dv, H);
+    h->att_dk_h = d.att_split_key ? h->att_dk / H : h->att_dk;
+    expect(h, "tdnn/attention/query", {H, h->att_dk_h});
+    const int sc = add_simple_op(h, OP_ATT_SCORES, key, -1, true, 14, H);
+    const int sm = add_simple_op(h, OP_ATT_SOFTMAX, sc, -1, true, 14, H);
+    add_node(h, "attention_weights", (int)h->ops.size() - 1, -1, true);
+    h->pool_dim = 2 * (d.att_split_value ? h->att_dv : h->att_dv * H);
+    pooled = add_simple_op(h, OP_ATT_POOL, val, sm, false, 0, h->pool_dim);
+    add_node(h, "att_output_before_nonlinear", (int)h->ops.size() - 1, -1);
+    if (d.att_apply_nonlinear) {                                           // model/pooling.py:222-229
+      h->post_bn_scope = "tdnn/attention/att_post_bn";
+      expect_bn(h, h->post_bn_scope, h->pool_dim);
+      if (act == ACT_PRELU) {
+        h->post_alpha_name = "tdnn/attention/att_post_relu/alpha";
+        expect(h, h->post_alpha_name, {h->pool_dim});
+      }
+      pooled = add_simple_op(h, OP_AFFINE_ACT, pooled, -1, false, 0, h->pool_dim);
+      add_node(h, "att_post_bn", (int)h->ops.size() - 1, 1);
+      add_node(h, "att_post_relu", (int)h->ops.size() - 1, 2);
+    }
+    add_node(h, "pooling", (int)h->ops.size() - 1, d.att_apply_nonlinear ? 2 : -1);
+  } else {
+    return fail(h, XV_ERR_UNSUPPORTED, "Not implement pooling_type %d", d.pooling_type);
+  }
+  v = add_layer(h, "tdnn/tdnn6", "tdnn6", false, 1, h->pool_dim, C, true, act, pooled, false, 0);
+  v = add_layer(h, "tdnn/tdnn7", "tdnn7", false, 1, C, d.num_nodes_last_layer, !d.last_layer_no_bn,
+                d.last_layer_linear ? ACT_NONE : act, v, false, 0);
+  if (d.feature_norm) {                                                     // model/trainer.py:400-403
+    add_simple_op(h, OP_L2_SCALE, v, -1, false, 0, d.num_nodes_last_layer);
+    add_node(h, "output", (int)h->ops.size() - 1, -1);
+  } else {
+    const int last = (int)h->ops.size() - 1;
+    add_node(h, "output", last, h->layers[h->ops[last].layer].final_stage());
+  }
+  return XV_OK;
+}
+
+const HostTensor& T(const xv_handle* h, const std::string& n) { return h->tensors.at(n); }
+
+// s = gamma / sqrt(var + eps), t = beta - mean * s   (inference BN as one multiply-add)
+void bn_fold(const xv_handle* h, const std::string& scope, int n, std::vector<double>& s, std::vector<double>& t) {
+  const auto& g = T(h, scope + "/gamma").data;
+  const auto& b = T(h, scope + "/beta").data;
+  const auto& m = T(h, scope + "/moving_mean").data;
+  const auto& v = T(h, scope + "/moving_variance").data;
+  s.resize(n); t.resize(n);
+  for (int i = 0; i < n; ++i) {
+    s[i] = (double)g[i] / std::sqrt((double)v[i] + kBnEps);
+    t[i] = (double)b[i] - (double)m[i] * s[i];
+  }
+}
+
+int upload_layer(xv_handle* h, Layer& L) {
+  const int K = L.w * L.cin, N = L.cout;
+  L.Kpad = (int)align_up(K, 32);
+  L.Npad = (int)align_up(N, 128);
+  const auto& W = T(h, L.kernel_name).data;      // [K][N] (HWIO flattened k-major / [in,out])
+  const auto& bias = T(h, L.bias_name).data;
+  std::vector<float> vec((size_t)5 * N, 0.f);
+  for (int n = 0; n < N; ++n) { vec[n] = bias[n]; vec[(size_t)4 * N + n] = 1.f; }
+  if (L.has_bn) {
+    std::vector<double> s, t;
+    bn_fold(h, L.bn_scope, N, s, t);
+    for (int n = 0; n < N; ++n) {
+      vec[(size_t)N + n] = (float)s[n];
+      vec[(size_t)2 * N + n] = (float)((double)bias[n] * s[n] + t[n]);
+    }
+  } else {
+    for (int n = 0; n < N; ++n) { vec[(size_t)N + n] = 1.f; vec[(size_t)2 * N + n] = bias[n]; }
+  }
+  if (!L.alpha_name.empty()) {
+    const auto& a = T(h, L.alpha_name).data;
+    for (int n = 0; n < N; ++n) vec[(size_t)3 * N + n] = a[n];
+  }
+  XV_HIP(h, L.vec.alloc(vec.size() * sizeof(float)));
+  XV_HIP(h, hipMemcpy(L.vec.p, vec.data(), vec.size() * sizeof(float), hipMemcpyHostToDevice));
+
+  const size_t elems = (size_t)L.Npad * L.Kpad;
+  if (h->desc.precision == XV_PREC_F32) {
+    std::vector<float> wt(elems, 0.f);
+    for (int k = 0; k < K; ++k)
+      for (int n = 0; n < N; ++n) wt[(size_t)n * L.Kpad + k] = W[(size_t)k * N + n];
+    XV_HIP(h, L.wt.alloc(elems * sizeof(float)));
+    XV_HIP(h, hipMemcpy(L.wt.p, wt.data(), elems * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    std::vector<uint16_t> hi(elems, 0), lo(elems, 0);
+    for (int k = 0; k < K; ++k)
+      for (int n = 0; n < N; ++n) {
+        const float wv = W[(size_t)k * N + n];
+        const uint16_t a = f32_to_bf16_rn(wv);
+        hi[(size_t)n * L.Kpad + k] = a;
+        lo[(size_t)n * L.Kpad + k] = f32_to_bf16_rn(wv - bf16_to_f32(a));
+      }
+    XV_HIP(h, L.whi.alloc(elems * 2));
+    XV_HIP(h, L.wlo.alloc(elems * 2));
+    XV_HIP(h, hipMemcpy(L.whi.p, hi.data(), elems * 2, hipMemcpyHostToDevice));
+    XV_HIP(h, hipMemcpy(L.wlo.p, lo.data(), elems * 2, hipMemcpyHostToDevice));
+  }
+  return XV_OK;
+}
+
+int64_t value_rows(const xv_handle* h, int vid, int64_t F0, int B) {
+  const Value& v = h->values[vid];
+  return v.frame_level ? F0 - (int64_t)B * v.ctx : B;
+}
+
+int64_t value_bytes(const xv_handle* h, int vid, int64_t F0, int B) {
+  const Value& v = h->values[vid];
+  return align_up((value_rows(h, vid, F0, B) + kSlackRows) * (int64_t)v.cols * 4, kAlign);
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+extern "C" {
+
+const char* xv_version(void) { return "xvec_hip 0.1 gfx950"; }
+
+const char* xv_last_error(const xv_handle* h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int xv_create(const xv_model_desc* desc, int device, xv_handle** out) {
+  if (!desc || !out) return fail(nullptr, XV_ERR_INVALID, "xv_create: null argument");
+  *out = nullptr;
+  if (desc->struct_size != (int32_t)sizeof(xv_model_desc))
+    return fail(nullptr, XV_ERR_INVALID, "xv_create: xv_model_desc size %d != %zu (ABI mismatch)", desc->struct_size,
+                sizeof(xv_model_desc));
+  if (desc->network_type != XV_NET_TDNN)
+    return fail(nullptr, XV_ERR_UNSUPPORTED, "Not implement network_type %d (only tdnn)", desc->network_type);
+  if (desc->feat_dim < 1 || desc->channels < 1 || desc->num_nodes_pooling_layer < 1 || desc->num_nodes_last_layer < 1)
+    return fail(nullptr, XV_ERR_INVALID, "xv_create: non-positive layer width");
+  if (desc->precision != XV_PREC_F32 && desc->precision != XV_PREC_BF16X3)
+    return fail(nullptr, XV_ERR_INVALID, "xv_create: unknown precision %d", desc->precision);
+  if (desc->relu_type < XV_ACT_RELU || desc->relu_type > XV_ACT_PRELU)
+    return fail(nullptr, XV_ERR_INVALID, "xv_create: unknown relu_type %d", desc->relu_type);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return fail(nullptr, XV_ERR_HIP, "xv_create: HIP device %d not available (%d visible)", device, ndev);
+  xv_handle* h = new (std::nothrow) xv_handle();
+  if (!h) return fail(nullptr, XV_ERR_HIP, "xv_create: out of host memory");
+  h->desc = *desc;
+  h->device = device;
+  const int rc = build_graph(h);
+  if (rc != XV_OK) {
+    g_last_error = h->err;
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return XV_OK;
+}
+
+int xv_set_tensor(xv_handle* h, const char* tf_name, const float* host, const int64_t* shape, int rank) {
+  if (!h) return fail(nullptr, XV_ERR_INVALID, "xv_set_tensor: null handle");
+  if (!tf_name || !host || !shape || rank < 1) return fail(h, XV_ERR_INVALID, "xv_set_tensor: null argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->finalized) return fail(h, XV_ERR_STATE, "xv_set_tensor after xv_finalize");
+  auto it = h->tensors.find(tf_name);
+  if (it == h->tensors.end()) return fail(h, XV_ERR_INVALID, "variable '%s' is not part of the predict graph", tf_name);
+  HostTensor& t = it->second;
+  bool same = (int)t.shape.size() == rank;
+  int64_t n = 1;
+  for (int i = 0; i < rank; ++i) {
+    if (same && t.shape[i] != shape[i]) same = false;
+    n *= shape[i];
+  }
+  if (!same) {
+    std::string exp, got;
+    for (auto s : t.shape) exp += std::to_string(s) + ",";
+    for (int i = 0; i < rank; ++i) got += std::to_string(shape[i]) + ",";
+    return fail(h, XV_ERR_INVALID, "variable '%s': expected shape [%s] got [%s]", tf_name, exp.c_str(), got.c_str());
+  }
+  t.data.assign(host, host + n);
+  t.set = true;
+  return XV_OK;
+}
+
+int xv_finalize(xv_handle* h) {
+  if (!h) return fail(nullptr, XV_ERR_INVALID, "xv_finalize: null handle");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->finalized) return XV_OK;
+  for (const auto& kv : h->tensors)
+    if (!kv.second.set) return fail(h, XV_ERR_MISSING_TENSOR, "variable '%s' was never set", kv.first.c_str());
+  DeviceGuard g(h->device);
+  if (!g.ok) return fail(h, XV_ERR_HIP, "cannot select HIP device %d", h->device);
+  for (auto& L : h->layers) {
+    const int rc = upload_layer(h, L);
+    if (rc != XV_OK) return rc;
+  }
+  if (h->desc.pooling_type == XV_POOL_SELF_ATTENTION) {
+    const auto& q = T(h, "tdnn/attention/query").data;
+    XV_HIP(h, h->query.alloc(q.size() * sizeof(float)));
+    XV_HIP(h, hipMemcpy(h->query.p, q.data(), q.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (h->desc.att_apply_nonlinear) {
+      const int n = h->pool_dim;
+      std::vector<double> s, t;
+      bn_fold(h, h->post_bn_scope, n, s, t);
+      std::vector<float> vec((size_t)3 * n, 0.f);
+      for (int i = 0; i < n; ++i) { vec[i] = (float)s[i]; vec[(size_t)n + i] = (float)t[i]; }
+      if (!h->post_alpha_name.empty()) {
+        const auto& a = T(h, h->post_alpha_name).data;
+        for (int i = 0; i < n; ++i) vec[(size_t)2 * n + i] = a[i];
+      }
+      XV_HIP(h, h->post_vec.alloc(vec.size() * sizeof(float)));
+      XV_HIP(h, hipMemcpy(h->post_vec.p, vec.data(), vec.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
+  XV_HIP(h, hipDeviceSynchronize());
+  for (auto& kv : h->tensors) { kv.second.data.clear(); kv.second.data.shrink_to_fit(); }
+  h->finalized = true;
+  return XV_OK;
+}
+
+int xv_node_id(const xv_handle* h, const char* name) {
+  if (!h || !name) return XV_ERR_INVALID;
+  for (size_t i = 0; i < h->nodes.size(); ++i)
+    if (h->nodes[i].name == name) return (int)i;
+  return XV_ERR_INVALID;
+}
+
+int xv_node_context(const xv_handle* h, int node_id) {
+  if (!h || node_id < 0 || node_id >= (int)h->nodes.size()) return XV_ERR_INVALID;
+  const Op& op = h->ops[h->nodes[node_id].op];
+  const Value& v = h->values[op.out];
+  return v.frame_level ? v.ctx : 14;
+}
+
+int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int node_id, void* stream, xv_plan** out) {
+  if (!h) return fail(nullptr, XV_ERR_INVALID, "xv_plan_create: null handle");
+  if (!out || !frame_offsets) return fail(h, XV_ERR_INVALID, "xv_plan_create: null argument");
+  *out = nullptr;
+  if (!h->finalized) return fail(h, XV_ERR_STATE, "xv_plan_create before xv_finalize");
+  if (batch < 1) return fail(h, XV_ERR_INVALID, "xv_plan_create: batch %d < 1", batch);
+  if (node_id < 0 || node_id >= (int)h->nodes.size()) return fail(h, XV_ERR_INVALID, "xv_plan_create: bad node id %d", node_id);
+  if (frame_offsets[0] != 0) return fail(h, XV_ERR_INVALID, "frame_offsets[0] must be 0");
+  const Node& node = h->nodes[node_id];
+  const int need_ctx = xv_node_context(h, node_id);
+  bool uniform = true;
+  for (int b = 0; b < batch; ++b) {
+    const int64_t len = (int64_t)frame_offsets[b + 1] - frame_offsets[b];
+    if (len <= need_ctx)
+      return fail(h, XV_ERR_TOO_SHORT, "utterance %d has %lld frames; node '%s' needs more than %d", b, (long long)len,
+                  node.name.c_str(), need_ctx);
+    if (len != (int64_t)frame_offsets[1] - frame_offsets[0]) uniform = false;
+  }
+  const int64_t F0 = frame_offsets[batch];
+  if (F0 > (int64_t)1 << 30) return fail(h, XV_ERR_INVALID, "batch of %lld frames is too large for 32-bit row indices", (long long)F0);
+
+  // ops needed for this node (backward closure), then in topological (= creation) order
+  std::vector<char> need(h->ops.size(), 0);
+  std::vector<int> producer(h->values.size(), -1);
+  for (size_t i = 0; i < h->ops.size(); ++i) producer[h->ops[i].out] = (int)i;
+  std::vector<int> stack{node.op};
+  while (!stack.empty()) {
+    const int o = stack.back();
+    stack.pop_back();
+    if (need[o]) continue;
+    need[o] = 1;
+    for (int in : {h->ops[o].in0, h->ops[o].in1})
+      if (in > 0 && producer[in] >= 0) stack.push_back(producer[in]);
+  }
+
+  xv_plan* p = new (std::nothrow) xv_plan();
+  if (!p) return fail(h, XV_ERR_HIP, "out of host memory");
+  p->h = h;
+  p->offsets.assign(frame_offsets, frame_offsets + batch + 1);
+  p->uniform_len = uniform;
+  p->uniform_L = frame_offsets[1] - frame_offsets[0];
+
+  // liveness: last step index that reads each value
+  std::vector<int> order;
+  for (size_t i = 0; i < h->ops.size(); ++i) if (need[i]) order.push_back((int)i);
+  std::vector<int> last_use(h->values.size(), -1);
+  for (size_t s = 0; s < order.size(); ++s)
+    for (int in : {h->ops[order[s]].in0, h->ops[order[s]].in1})
+      if (in > 0) last_use[in] = (int)s;
+
+  // first-fit arena with release after last use
+  struct Block { int64_t off, size; };
+  std::vector<Block> free_list;
+  int64_t arena_top = 0;
+  std::vector<int64_t> voff(h->values.size(), -1), vsize(h->values.size(), 0);
+  auto arena_alloc = [&](int64_t size) -> int64_t {
+    for (size_t i = 0; i < free_list.size(); ++i)
+      if (free_list[i].size >= size) {
+        const int64_t off = free_list[i].off;
+        free_list[i].off += size;
+        free_list[i].size -= size;
+        if (free_list[i].size == 0) free_list.erase(free_list.begin() + i);
+        return off;
+      }
+    const int64_t off = arena_top;
+    arena_top += size;
+    return off;
+  };
+  auto arena_free = [&](int64_t off, int64_t size) {
+    free_list.push_back({off, size});
+    std::sort(free_list.begin(), free_list.end(), [](const Block& a, const Block& b) { return a.off < b.off; });
+    for (size_t i = 0; i + 1 < free_list.size();)
+      if (free_list[i].off + free_list[i].size == free_list[i + 1].off) {
+        free_list[i].size += free_list[i + 1].size;
+        free_list.erase(free_list.begin() + i + 1);
+      } else {
+        ++i;
+      }
+  };
+
+  int64_t total_flops = 0;
+  int64_t rowmap_elems = 0;
+  for (size_t s = 0; s < order.size(); ++s) {
+    const Op& op = h->ops[order[s]];
+    PlanStep st;
+    st.op = order[s];
+    st.to_out = (order[s] == node.op);
+    st.rows_in = op.in0 >= 0 ? value_rows(h, op.in0, F0, batch) : 0;
+    st.rows_out = value_rows(h, op.out, F0, batch);
+    st.in0_off = op.in0 == 0 ? -2 : (op.in0 > 0 ? voff[op.in0] : -1);
+    st.in1_off = op.in1 > 0 ? voff[op.in1] : -1;
+    if (op.kind == OP_GEMM) {
+      const Layer& L = h->layers[op.layer];
+      st.stage = st.to_out ? node.stage : L.final_stage();
+      st.M = (int)(st.rows_in - (L.w - 1));
+      if (L.w > 1) {
+        st.rowmap = (int)p->rowmap_off.size();
+        p->rowmap_off.push_back(rowmap_elems);
+        rowmap_elems += align_up(st.M, 64);
+      }
+      st.flops = 2 * st.rows_out * (int64_t)L.cout * L.w * L.cin;
+      st.bytes = 4 * (st.rows_in * L.cin + st.rows_out * L.cout + (int64_t)L.w * L.cin * L.cout);
+    } else if (op.kind == OP_AFFINE_ACT) {
+      st.stage = st.to_out ? node.stage : 2;
+      st.bytes = 8 * st.rows_out * h->values[op.out].cols;
+    } else if (op.kind == OP_STAT_POOL || op.kind == OP_ATT_POOL) {
+      st.bytes = 4 * (st.rows_in * h->values[op.in0].cols + st.rows_out * h->values[op.out].cols);
+      st.flops = 4 * st.rows_in * h->values[op.in0].cols;
+    } else if (op.kind == OP_ATT_SCORES) {
+      st.bytes = 4 * st.rows_in * h->values[op.in0].cols;
+      st.flops = 2 * st.rows_in * (int64_t)h->att_dk_h * h->desc.att_num_heads;
+    } else {
+      st.bytes = 8 * st.rows_out * h->values[op.out].cols;
+    }
+    total_flops += st.flops;
+    // softmax works in place on the scores buffer; everything else gets its own block
+    if (op.kind == OP_ATT_SOFTMAX) {
+      voff[op.out] = voff[op.in0];
+      vsize[op.out] = vsize[op.in0];
+      vsize[op.in0] = 0;                 // ownership moves to the softmax value
+      st.out_off = voff[op.out];
+    } else if (!st.to_out || node.att_weights) {
+      vsize[op.out] = value_bytes(h, op.out, F0, batch);
+      voff[op.out] = arena_alloc(vsize[op.out]);
+      st.out_off = voff[op.out];
+    }
+    if (st.to_out && !node.att_weights) st.out_off = -1;
+    p->steps.push_back(st);
+    for (int in : {op.in0, op.in1})
+      if (in > 0 && last_use[in] == (int)s && vsize[in] > 0) { arena_free(voff[in], vsize[in]); vsize[in] = 0; }
+  }
+
+  // output shape
+  const Op& top = h->ops[node.op];
+  const Value& vout = h->values[top.out];
+  xv_plan_info& I = p->info;
+  I.struct_size = (int32_t)sizeof(xv_plan_info);
+  I.node_id = node_id;
+  I.batch = batch;
+  I.in_frames = F0;
+  I.flops = total_flops;
+  if (node.att_weights) {
+    if (!uniform) {
+      delete p;
+      return fail(h, XV_ERR_INVALID, "attention_weights [b,h,l] needs utterances of equal length");
+    }
+    I.frame_level = 0;
+    I.out_rows = (int64_t)batch * h->desc.att_num_heads;
+    I.out_cols = p->uniform_L - vout.ctx;
+  } else {
+    I.frame_level = vout.frame_level ? 1 : 0;
+    I.out_rows = value_rows(h, top.out, F0, batch);
+    I.out_cols = vout.cols;
+  }
+  I.workspace_bytes = align_up(arena_top, kAlign) + kAlign;
+
+  // device index arrays
+  DeviceGuard g(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto bail = [&](hipError_t e, const char* what) {
+    const int rc = fail(h, XV_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    xv_plan_destroy(p);
+    return rc;
+  };
+  hipError_t e;
+  if ((e = p->d_offsets.alloc((size_t)(batch + 1) * 4)) != hipSuccess) return bail(e, "hipMalloc(offsets)");
+  if ((e = hipMemcpyAsync(p->d_offsets.p, p->offsets.data(), (size_t)(batch + 1) * 4, hipMemcpyHostToDevice, s)) != hipSuccess)
+    return bail(e, "hipMemcpyAsync(offsets)");
+  if (rowmap_elems > 0) {
+    if ((e = p->d_rowmaps.alloc((size_t)rowmap_elems * 4)) != hipSuccess) return bail(e, "hipMalloc(rowmaps)");
+    for (const PlanStep& st : p->steps) {
+      if (st.rowmap < 0) continue;
+      const Op& op = h->ops[st.op];
+      const Layer& L = h->layers[op.layer];
+      const int ctx_in = h->values[op.in0].ctx;
+      e = launch_build_rowmap(static_cast<const int32_t*>(p->d_offsets.p), batch, ctx_in, L.w,
+                              static_cast<int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.rowmap], st.M, s);
+      if (e != hipSuccess) return bail(e, "build_rowmap");
+    }
+  }
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+  *out = p;
+  return XV_OK;
+}
+
+int xv_plan_query(const xv_plan* p, xv_plan_info* info) {
+  if (!p || !info) return XV_ERR_INVALID;
+  *info = p->info;
+  return XV_OK;
+}
+
+void xv_plan_destroy(xv_plan* p) {
+  if (!p) return;
+  {
+    DeviceGuard g(p->h->device);
+    p->d_offsets.release();
+    p->d_rowmaps.release();
+  }
+  delete p;
+}
+
+static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat_ld, float* out, int64_t out_cap,
+                    void* workspace, int64_t ws_bytes, hipStream_t s, xv_kernel_time* times, int max_times) {
+  if (!h || !p) return fail(h, XV_ERR_INVALID, "xv_forward: null handle/plan");
+  if (p->h != h) return fail(h, XV_ERR_INVALID, "xv_forward: plan belongs to another handle");
+  if (!feats || !out) return fail(h, XV_ERR_INVALID, "xv_forward: null feature/output pointer");
+  if (feat_ld < h->desc.feat_dim) return fail(h, XV_ERR_INVALID, "xv_forward: feat_ld %d < feature_dim %d", feat_ld, h->desc.feat_dim);
+  if (out_cap < p->info.out_rows * p->info.out_cols)
+    return fail(h, XV_ERR_WORKSPACE, "xv_forward: output capacity %lld < %lld", (long long)out_cap,
+                (long long)(p->info.out_rows * p->info.out_cols));
+  if (ws_bytes < p->info.workspace_bytes || (!workspace && p->info.workspace_bytes > 0))
+    return fail(h, XV_ERR_WORKSPACE, "xv_forward: workspace %lld bytes < %lld", (long long)ws_bytes, (long long)p->info.workspace_bytes);
+  char* ws = reinterpret_cast<char*>(align_up((int64_t)reinterpret_cast<uintptr_t>(workspace), kAlign));
+  DeviceGuard g(h->device);
+  if (!g.ok) return fail(h, XV_ERR_HIP, "cannot select HIP device %d", h->device);
+  const int B = p->info.batch;
+  const int32_t* off = static_cast<const int32_t*>(p->d_offsets.p);
+  const xv_model_desc& d = h->desc;
+  const bool split = d.precision == XV_PREC_BF16X3;
+
+  std::vector<hipEvent_t> ev;
+  int ntimes = 0;
+  if (times) {
+    ev.resize(p->steps.size() + 1);
+    for (auto& e : ev) XV_HIP(h, hipEventCreate(&e));
+    XV_HIP(h, hipEventRecord(ev[0], s));
+  }
+
+  for (size_t si = 0; si < p->steps.size(); ++si) {
+    const PlanStep& st = p->steps[si];
+    const Op& op = h->ops[st.op];
+    auto in_ptr = [&](int64_t o) -> const float* {
+      return o == -2 ? feats : reinterpret_cast<const float*>(ws + o);
+    };
+    float* optr = st.out_off >= 0 ? reinterpret_cast<float*>(ws + st.out_off) : out;
+    const char* name = "op";
+    switch (op.kind) {
+      case OP_GEMM: {
+        const Layer& L = h->layers[op.layer];
+        name = L.ep[ST_AFFINE].c_str();
+        GemmArgs a{};
+        a.X = in_ptr(st.in0_off);
+        a.ldx = op.in0 == 0 ? feat_ld : L.cin;
+        a.cin = L.cin; a.M = st.M; a.K = L.w * L.cin; a.N = L.cout;
+        a.Wt = static_cast<const float*>(L.wt.p); a.Kpad = L.Kpad; a.Npad = L.Npad;
+        const bool bn_stage = st.stage >= ST_BN;
+        a.scale = (bn_stage || !L.has_bn) ? L.d_scale() : L.d_ones();
+        a.shift = (bn_stage || !L.has_bn) ? L.d_shift() : L.d_bias();
+        a.act = (st.stage == ST_ACT) ? L.act : ACT_NONE;
+        a.alpha = (a.act == ACT_PRELU) ? L.d_alpha() : nullptr;
+        a.rowmap = st.rowmap >= 0 ? static_cast<const int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.rowmap] : nullptr;
+        a.Y = optr; a.ldy = L.cout;
+        const bool aligned = op.in0 != 0 && (a.ldx % 4 == 0) && (a.K % 4 == 0);
+        if (split && op.in0 != 0) {
+          return fail(h, XV_ERR_UNSUPPORTED, "bf16x3 path not built yet");
+        }
+        XV_HIP(h, launch_gemm_f32(a, aligned, s));
+        break;
+      }
+      case OP_STAT_POOL: {
+        name = "stat_pool";
+        const Value& vi = h->values[op.in0];
+        XV_HIP(h, launch_stat_pool(in_ptr(st.in0_off), vi.cols, vi.cols, off, B, vi.ctx, optr, 2 * vi.cols, s));
+        break;
+      }
+      case OP_ATT_SCORES: {
+        name = "att_scores";
+        const Value& vi = h->values[op.in0];
+        const float scale = d.att_use_scale ? 1.0f / std::sqrt((float)h->att_dk_h) : 1.0f;   // model/pooling.py:193-194
+        XV_HIP(h, launch_att_scores(in_ptr(st.in0_off), vi.cols, st.rows_in, static_cast<const float*>(h->query.p),
+                                    d.att_num_heads, h->att_dk_h, d.att_split_key, scale,
+                                    reinterpret_cast<float*>(ws + st.out_off), s));
+        break;
+      }
+      case OP_ATT_SOFTMAX: {
+        name = "att_softmax";
+        float* sc = reinterpret_cast<float*>(ws + st.out_off);
+        XV_HIP(h, launch_att_softmax(sc, d.att_num_heads, off, B, 14, s));
+        if (st.to_out) XV_HIP(h, launch_att_weights_out(sc, d.att_num_heads, off, B, 14, out, s));
+        break;
+      }
+      case OP_ATT_POOL: {
+        name = "att_pool";
+        const Value& vv = h->values[op.in0];
+        XV_HIP(h, launch_att_pool(in_ptr(st.in0_off), vv.cols, vv.cols, in_ptr(st.in1_off), d.att_num_heads,
+                                  d.att_split_value, off, B, vv.ctx, optr, h->pool_dim, s));
+        break;
+      }
+      case OP_AFFINE_ACT: {
+        name = "att_post";
+        const int n = h->pool_dim;
+        const float* vec = static_cast<const float*>(h->post_vec.p);
+        const int a = st.stage >= 2 ? act_of(d) : ACT_NONE;
+        XV_HIP(h, launch_affine_act(in_ptr(st.in0_off), n, B, n, vec, vec + n,
+                                    (a == ACT_PRELU) ? vec + 2 * n : nullptr, a, optr, n, s));
+        break;
+      }
+      case OP_L2_SCALE: {
+        name = "l2_scale";
+        XV_HIP(h, launch_l2_scale(in_ptr(st.in0_off), B, h->values[op.out].cols, d.feature_scaling_factor, optr, s));
+        break;
+      }
+      default:
+        return fail(h, XV_ERR_STATE, "unknown op kind %d", op.kind);
+    }
+    if (times) {
+      XV_HIP(h, hipEventRecord(ev[si + 1], s));
+      if (ntimes < max_times) {
+        xv_kernel_time& t = times[ntimes++];
+        memset(&t, 0, sizeof(t));
+        snprintf(t.name, sizeof(t.name), "%s", name);
+        t.flops = st.flops;
+        t.bytes = st.bytes;
+      }
+    }
+  }
+  if (times) {
+    XV_HIP(h, hipEventSynchronize(ev.back()));
+    for (int i = 0; i < ntimes; ++i) XV_HIP(h, hipEventElapsedTime(&times[i].ms, ev[i], ev[i + 1]));
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return ntimes;
+  }
+  return XV_OK;
+}
+
+int xv_forward(xv_handle* h, const xv_plan* p, const float* feats_dev, int feat_ld, float* out_dev, int64_t out_capacity,
+               void* workspace, int64_t workspace_bytes, void* stream) {
+  return run_plan(h, p, feats_dev, feat_ld, out_dev, out_capacity, workspace, workspace_bytes,
+                  static_cast<hipStream_t>(stream), nullptr, 0);
+}
+
+int xv_forward_timed(xv_handle* h, const xv_plan* p, const float* feats_dev, int feat_ld, float* out_dev,
+                     int64_t out_capacity, void* workspace, int64_t workspace_bytes, void* stream,
+                     xv_kernel_time* entries, int max_entries) {
+  if (!entries || max_entries < 1) return fail(h, XV_ERR_INVALID, "xv_forward_timed: no entry buffer");
+  return run_plan(h, p, feats_dev, feat_ld, out_dev, out_capacity, workspace, workspace_bytes,
+                  static_cast<hipStream_t>(stream), entries, max_entries);
+}
+
+void xv_destroy(xv_handle* h) {
+  if (!h) return;
+  {
+    DeviceGuard g(h->device);
+    for (auto& L : h->layers) { L.wt.release(); L.whi.release(); L.wlo.release(); L.vec.release(); }
+    h->query.release();
+    h->post_vec.release();
+  }
+  delete h;
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+"""Host-side mirror of the reference's predict surface: `Trainer(params, model_dir, dim,
+single_cpu=True)`, `.build("predict")`, `.predict(features)`, `.close()`
+(model/trainer.py:87-219, 309-338, 379-383, 277-295, 886-913, 270-275), so that
+egs/voxceleb/v1/nnet/lib/extract.py:56-57,81-89,95 runs unchanged against it.
+
+Where the reference builds a TF graph and calls sess.run, this class creates an
+`xv_handle` in libxvec_hip.so (include/xvec_hip.h), uploads the checkpoint variables by
+their TensorFlow names and runs the HIP kernels.  PyTorch is used only for device memory
+and the stream.  There is no CPU path: without the HIP library or a GPU this raises.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+from . import _lib
+from . import model_io
+
+_PRECISIONS = {"f32": _lib.XV_PREC_F32, "bf16x3": _lib.XV_PREC_BF16X3}
+DEFAULT_PRECISION = "f32"
+
+
+def _relu_type(params):
+    t = params.dict.get("network_relu_type")
+    return {"prelu": _lib.XV_ACT_PRELU, "lrelu": _lib.XV_ACT_LRELU}.get(t, _lib.XV_ACT_RELU)
+
+
+def _endpoint_index(name, what):
+    """'tdnn4_relu' -> 4 (attention key/value inputs must be frame-level relu endpoints)."""
+    for i in (3, 4, 5):
+        if name == "tdnn%d_relu" % i:
+            return i
+    raise NotImplementedError("%s=%r: only tdnn3_relu/tdnn4_relu/tdnn5_relu are supported" % (what, name))
+
+
+class Trainer(object):
+    """Predict-only counterpart of model/trainer.py `Trainer`."""
+
+    def __init__(self, params, model_dir, dim, num_speakers=None, single_cpu=False, num_gpus=1,
+                 device=None, precision=None):
+        # model/trainer.py:100-110 network dispatch.  Only the TDNN is on this round's hot path.
+        self.network_type = params.network_type
+        if params.network_type != "tdnn":
+            if params.network_type in ("tdnn-s", "extended_tdnn", "resnet_18"):
+                raise NotImplementedError("%s network is not built yet (SURVEY.md 8f)" % params.network_type)
+            raise NotImplementedError("Not implement %s network" % params.network_type)
+        self.params = params
+        self.model = os.path.join(model_dir, "nnet") if model_dir is not None else None
+        self.dim = int(dim)
+        self.num_speakers = num_speakers
+        self.is_built = False
+        self.is_loaded = False
+        self.first_feature_split_alert = True
+        self.embeddings = None            # name of the endpoint predict() returns
+        self._precision = precision or os.environ.get("XVEC_PRECISION", DEFAULT_PRECISION)
+        if self._precision not in _PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self._device_index = int(device)
+        self._lib = None
+        self._h = None
+        self._plans = {}
+        self._ws = None
+        self._step = None
+
+    # ------------------------------------------------------------------ graph build
+    def build(self, mode, noupdate_var_list=None):
+        """model/trainer.py:309-338.  Only `predict` exists here (training is out of scope)."""
+        assert mode == "train" or mode == "valid" or mode == "predict"
+        if mode != "predict":
+            raise NotImplementedError("only build('predict') is implemented (extraction path)")
+        p = self.params
+        # defaults the reference writes into params while building (model/tdnn.py:114-116,152-154,163-164,173-174)
+        if "num_nodes_pooling_layer" not in p.dict:
+            p.dict["num_nodes_pooling_layer"] = 1500
+        if "num_nodes_last_layer" not in p.dict:
+            p.dict["num_nodes_last_layer"] = 512
+        if "last_layer_no_bn" not in p.dict:
+            p.dict["last_layer_no_bn"] = False
+        if "last_layer_linear" not in p.dict:
+            p.dict["last_layer_linear"] = False
+        if p.pooling_type not in ("statistics_pooling", "self_attention"):
+            raise NotImplementedError("Not implement %s pooling" % p.pooling_type)     # model/pooling.py:23
+        if "feature_norm" in p.dict and p.feature_norm:
+            assert "feature_scaling_factor" in p.dict, \
+                "If feature normalization is applied, scaling factor is necessary."      # trainer.py:401
+        self.embeddings = p.embedding_node                                              # trainer.py:380
+        self.is_built = True
+
+    def set_embedding(self, embedding_node):
+        """model/trainer.py:305-307."""
+        self.params.embedding_node = embedding_node
+        self.embeddings = embedding_node
+
+    def _make_desc(self, channels):
+        p = self.params
+        d = _lib.ModelDesc()
+        d.struct_size = C.sizeof(_lib.ModelDesc)
+        d.network_type = 0
+        d.feat_dim = self.dim
+        d.channels = int(channels)
+        d.pooling_type = _lib.XV_POOL_SELF_ATTENTION if p.pooling_type == "self_attention" else _lib.XV_POOL_STATISTICS
+        d.relu_type = _relu_type(p)
+        d.num_nodes_pooling_layer = int(p.dict["num_nodes_pooling_layer"])
+        d.num_nodes_last_layer = int(p.dict["num_nodes_last_layer"])
+        d.last_layer_no_bn = int(bool(p.dict["last_layer_no_bn"]))
+        d.last_layer_linear = int(bool(p.dict["last_layer_linear"]))
+        d.feature_norm = int(bool(p.dict.get("feature_norm", False)))
+        d.feature_scaling_factor = float(p.dict.get("feature_scaling_factor", 1.0))
+        d.precision = _PRECISIONS[self._precision]
+        if p.pooling_type == "self_attention":
+            kn = list(p.att_key_num_nodes)
+            vn = list(p.att_value_num_nodes)
+            if not 1 <= len(kn) <= _lib.XV_MAX_ATT_LAYERS or len(vn) > _lib.XV_MAX_ATT_LAYERS:
+                raise NotImplementedError("attention key/value networks deeper than %d layers" % _lib.XV_MAX_ATT_LAYERS)
+            d.att_key_input = _endpoint_index(p.att_key_input, "att_key_input")
+            d.att_value_input = _endpoint_index(p.att_value_input, "att_value_input")
+            d.att_num_key_layers = len(kn)
+            for i, n in enumerate(kn):
+                d.att_key_num_nodes[i] = int(n)
+            d.att_key_network_type = int(p.att_key_network_type)
+            d.att_num_value_layers = len(vn)
+            for i, n in enumerate(vn):
+                d.att_value_num_nodes[i] = int(n)
+            d.att_value_network_type = int(p.att_value_network_type)
+            d.att_apply_nonlinear = int(bool(p.att_apply_nonlinear))
+            d.att_use_scale = int(bool(p.att_use_scale))
+            d.att_num_heads = int(p.att_num_heads)
+            d.att_split_value = int(bool(p.att_split_value))
+            d.att_split_key = int(bool(p.att_split_key))
+        return d
+
+    # ------------------------------------------------------------------ weights
+    def load(self):
+        """model/trainer.py:277-295: restore the checkpoint named by <model>/nnet/checkpoint."""
+        if not self.is_built:
+            sys.exit("The graph has not been build. Cannot load the models.")
+        weights, step = (None, None)
+        if self.model is not None:
+            weights, step = model_io.load_weights(self.model)
+        if weights is None:
+            sys.exit("Failed to find a checkpoint in {}".format(self.model))
+        self.load_weights(weights, step)
+        return step
+
+    def load_weights(self, weights, step=0):
+        """Upload a {TF variable name: array} dict (what Saver.restore does from a checkpoint)."""
+        if not self.is_built:
+            sys.exit("The graph has not been build. Cannot load the models.")
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the x-vector path has no CPU fallback")
+        self._torch = torch
+        self._lib = _lib.load()
+        self._release()
+        k1 = np.asarray(weights["tdnn/tdnn1_conv/kernel"])
+        desc = self._make_desc(channels=k1.shape[-1])
+        h = C.c_void_p()
+        _lib.check(self._lib.xv_create(C.byref(desc), self._device_index, C.byref(h)))
+        self._h = h
+        try:
+            unused = []
+            for name, arr in weights.items():
+                a = np.ascontiguousarray(np.asarray(arr), dtype=np.float32)
+                shape = (C.c_int64 * a.ndim)(*a.shape)
+                rc = self._lib.xv_set_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
+                if rc < 0:
+                    msg = self._lib.xv_last_error(self._h).decode()
+                    if "not part of the predict graph" in msg:
+                        unused.append(name)        # e.g. softmax/output layer, optimizer slots
+                        continue
+                    raise _lib.XvError(rc, msg)
+            _lib.check(self._lib.xv_finalize(self._h), self._h)
+        except Exception:
+            self._release()
+            raise
+        self._unused_variables = unused
+        self._step = step
+        self.is_loaded = True
+
+    # ------------------------------------------------------------------ device-level predict
+    def _plan(self, offsets, node):
+        key = (node, offsets.tobytes())
+        ent = self._plans.get(key)
+        if ent is not None:
+            return ent
+        nid = self._lib.xv_node_id(self._h, node.encode())
+        if nid < 0:
+            raise KeyError(node)                       # endpoints[params.embedding_node] (trainer.py:380)
+        torch = self._torch
+        off = np.ascontiguousarray(offsets, dtype=np.int32)
+        plan = C.c_void_p()
+        stream = torch.cuda.current_stream(self._device_index).cuda_stream
+        rc = self._lib.xv_plan_create(self._h, off.ctypes.data_as(C.c_void_p), len(off) - 1, nid,
+                                      C.c_void_p(stream), C.byref(plan))
+        if rc == _lib.XV_ERR_TOO_SHORT:
+            raise ValueError(self._lib.xv_last_error(self._h).decode())
+        _lib.check(rc, self._h)
+        info = _lib.PlanInfo()
+        _lib.check(self._lib.xv_plan_query(plan, C.byref(info)))
+        if len(self._plans) >= 64:                     # bounded cache of batch geometries
+            _, (old, _) = self._plans.popitem()
+            self._lib.xv_plan_destroy(old)
+        self._plans[key] = (plan, info)
+        return plan, info
+
+    def _workspace(self, nbytes):
+        torch = self._torch
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda:%d" % self._device_index)
+        return self._ws
+
+    def predict_packed(self, feats_dev, offsets, node=None, timed=False):
+        """Device-resident entry: `feats_dev` is a float32 CUDA tensor [total_frames, ld] holding
+        the utterances back to back, `offsets` the B+1 frame offsets.  Returns a CUDA tensor
+        [B, E] (segment-level node) or [total_out_frames, E] (frame-level node), enqueued on
+        the current stream.  With timed=True returns (out, [(kernel, ms, flops, bytes), ...])."""
+        if not self.is_loaded:
+            self._lazy_load()
+        torch = self._torch
+        node = node or self.embeddings
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        assert feats_dev.is_cuda and feats_dev.dtype == torch.float32 and feats_dev.dim() == 2
+        assert feats_dev.is_contiguous()
+        assert feats_dev.shape[0] == int(offsets[-1]), "offsets[-1] must equal the number of packed frames"
+        if feats_dev.shape[1] < self.dim:
+            raise ValueError("features have %d columns, the network needs %d" % (feats_dev.shape[1], self.dim))
+        plan, info = self._plan(offsets, node)
+        ws = self._workspace(info.workspace_bytes + 256)
+        out = torch.empty((int(info.out_rows), int(info.out_cols)), dtype=torch.float32, device=feats_dev.device)
+        stream = torch.cuda.current_stream(self._device_index).cuda_stream
+        args = (self._h, plan, C.c_void_p(feats_dev.data_ptr()), int(feats_dev.shape[1]),
+                C.c_void_p(out.data_ptr()), out.numel(), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream))
+        if not timed:
+            _lib.check(self._lib.xv_forward(*args), self._h)
+            return out
+        ent = (_lib.KernelTime * 64)()
+        n = _lib.check(self._lib.xv_forward_timed(*(args + (ent, 64))), self._h)
+        return out, [(ent[i].name.decode(), float(ent[i].ms), int(ent[i].flops), int(ent[i].bytes)) for i in range(n)]
+
+    def plan_info(self, offsets, node=None):
+        if not self.is_loaded:
+            self._lazy_load()
+        _, info = self._plan(np.ascontiguousarray(offsets, dtype=np.int32), node or self.embeddings)
+        return {f[0]: getattr(info, f[0]) for f in info._fields_}
+
+    def _lazy_load(self):
+        # model/trainer.py:891-895
+        if self.model is not None and os.path.isfile(os.path.join(self.model, "checkpoint")):
+            self.load()
+        else:
+            sys.exit("Cannot find model in %s" % self.model)
+
+    # ------------------------------------------------------------------ Trainer.predict
+    def predict(self, features):
+        """Output the embeddings (model/trainer.py:886-913): `features` is [T,d] or [B,T,d]
+        float; columns beyond `dim` are dropped; returns [E] / [B,E] for segment-level nodes
+        and [T',E] / [B,T',E] for frame-level nodes."""
+        if not self.is_loaded:
+            self._lazy_load()
+        features = np.asarray(features)
+        rank = len(features.shape)
+        assert (rank == 2 or rank == 3)
+        if rank == 2:
+            features = np.expand_dims(features, axis=0)
+        if self.first_feature_split_alert and features.shape[-1] != self.dim:
+            self.first_feature_split_alert = False
+        if features.shape[-1] < self.dim:
+            raise ValueError("features have %d columns, the network needs %d" % (features.shape[-1], self.dim))
+        torch = self._torch
+        b, t, d = features.shape
+        host = np.ascontiguousarray(features, dtype=np.float32).reshape(b * t, d)
+        with torch.cuda.device(self._device_index):
+            dev = torch.from_numpy(host).to("cuda:%d" % self._device_index)
+            offsets = np.arange(b + 1, dtype=np.int32) * t
+            node = self.embeddings
+            out = self.predict_packed(dev, offsets, node)
+            _, info = self._plan(offsets, node)
+            emb = out.cpu().numpy()
+        if node == "attention_weights":
+            emb = emb.reshape(b, -1, emb.shape[-1])
+        elif info.frame_level:
+            emb = emb.reshape(b, -1, emb.shape[-1])
+        if rank == 2:
+            emb = np.squeeze(emb, axis=0)
+        return emb
+
+    # ------------------------------------------------------------------ teardown
+    def _release(self):
+        if self._lib is not None:
+            for plan, _ in self._plans.values():
+                self._lib.xv_plan_destroy(plan)
+            self._plans = {}
+            if self._h is not None:
+                self._lib.xv_destroy(self._h)
+                self._h = None
+        self._ws = None
+        self.is_loaded = False
+
+    def close(self):
+        """model/trainer.py:270-275."""
+        self._release()
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
