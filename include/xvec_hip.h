@@ -152,18 +152,22 @@ void xv_plan_destroy(xv_plan* p);
 int xv_forward(xv_handle* h, const xv_plan* p, const float* feats_dev, int feat_ld, float* out_dev,
                int64_t out_capacity, void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Per-kernel timing of one xv_forward, measured with hipEvents on `stream` (synchronises;
- * for bench.py / profiling only).  Writes up to `max_entries` records and returns the count
- * (>= 0) or a negative xv_status.  flops/bytes are the ALGORITHMIC figures of the launch. */
+/* Per-kernel timing with hipEvents on the launch stream, for bench.py (roofline numbers).
+ * Between xv_profile_begin and xv_profile_end every xv_forward on this handle brackets each
+ * kernel launch with two events from a pool of `max_events` (no host synchronisation; forwards
+ * that no longer fit in the pool run unprofiled).  xv_profile_end synchronises on the recorded
+ * events and returns one record per distinct kernel launch shape: mean launch duration over the
+ * profiled forwards and the ALGORITHMIC flops / bytes of one launch (2*M*N*K; inputs + outputs +
+ * weights once).  Returns the record count (>= 0) or a negative xv_status. */
 typedef struct {
   char name[48];
-  float ms;
+  float ms;          /* mean duration of one launch                                        */
+  int32_t launches;  /* launches averaged                                                  */
   int64_t flops;
   int64_t bytes;
 } xv_kernel_time;
-int xv_forward_timed(xv_handle* h, const xv_plan* p, const float* feats_dev, int feat_ld, float* out_dev,
-                     int64_t out_capacity, void* workspace, int64_t workspace_bytes, void* stream,
-                     xv_kernel_time* entries, int max_entries);
+int xv_profile_begin(xv_handle* h, int max_events);
+int xv_profile_end(xv_handle* h, xv_kernel_time* entries, int max_entries, int* n_forwards);
 
 /* Trainer.close (model/trainer.py:270-275). */
 void xv_destroy(xv_handle* h);

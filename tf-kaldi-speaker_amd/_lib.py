@@ -22,7 +22,7 @@ XV_POOL_SELF_ATTENTION = 1
 XV_ACT_RELU, XV_ACT_LRELU, XV_ACT_PRELU = 0, 1, 2
 
 EXPORTS = ["xv_version", "xv_create", "xv_set_tensor", "xv_finalize", "xv_node_id", "xv_node_context",
-           "xv_plan_create", "xv_plan_query", "xv_plan_destroy", "xv_forward", "xv_forward_timed",
+           "xv_plan_create", "xv_plan_query", "xv_plan_destroy", "xv_forward", "xv_profile_begin", "xv_profile_end",
            "xv_destroy", "xv_last_error"]
 
 
@@ -52,7 +52,8 @@ class PlanInfo(C.Structure):
 
 
 class KernelTime(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("ms", C.c_float), ("flops", C.c_int64), ("bytes", C.c_int64)]
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_float), ("launches", C.c_int32),
+                ("flops", C.c_int64), ("bytes", C.c_int64)]
 
 
 _lib = None
@@ -87,7 +88,8 @@ def load():
     lib.xv_plan_destroy.argtypes = [vp]
     lib.xv_plan_destroy.restype = None
     lib.xv_forward.argtypes = [vp, vp, vp, i32, vp, i64, vp, i64, vp]
-    lib.xv_forward_timed.argtypes = [vp, vp, vp, i32, vp, i64, vp, i64, vp, C.POINTER(KernelTime), i32]
+    lib.xv_profile_begin.argtypes = [vp, i32]
+    lib.xv_profile_end.argtypes = [vp, C.POINTER(KernelTime), i32, C.POINTER(i32)]
     lib.xv_destroy.argtypes = [vp]
     lib.xv_destroy.restype = None
     for n in EXPORTS:

@@ -135,6 +135,13 @@ struct xv_handle {
   std::string post_bn_scope, post_alpha_name;
   DevBuf post_vec;              // [scale | shift | alpha] each pool_dim floats
   int pool_dim = 0;
+  // optional per-op event profiling (xv_profile_begin / xv_profile_end)
+  struct ProfRec { hipEvent_t e0, e1; const xv_plan* plan; int step; };
+  bool profiling = false;
+  std::vector<hipEvent_t> prof_pool;
+  size_t prof_next = 0;
+  std::vector<ProfRec> prof_recs;
+  int prof_forwards = 0;
 };
 
 struct PlanStep {
@@ -742,8 +749,22 @@ void xv_plan_destroy(xv_plan* p) {
   delete p;
 }
 
+static const char* step_name(const xv_handle* h, const PlanStep& st) {
+  const Op& op = h->ops[st.op];
+  switch (op.kind) {
+    case OP_GEMM: return h->layers[op.layer].ep[ST_AFFINE].c_str();
+    case OP_STAT_POOL: return "stat_pool";
+    case OP_ATT_SCORES: return "att_scores";
+    case OP_ATT_SOFTMAX: return "att_softmax";
+    case OP_ATT_POOL: return "att_pool";
+    case OP_AFFINE_ACT: return "att_post";
+    case OP_L2_SCALE: return "l2_scale";
+    default: return "op";
+  }
+}
+
 static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat_ld, float* out, int64_t out_cap,
-                    void* workspace, int64_t ws_bytes, hipStream_t s, xv_kernel_time* times, int max_times) {
+                    void* workspace, int64_t ws_bytes, hipStream_t s) {
   if (!h || !p) return fail(h, XV_ERR_INVALID, "xv_forward: null handle/plan");
   if (p->h != h) return fail(h, XV_ERR_INVALID, "xv_forward: plan belongs to another handle");
   if (!feats || !out) return fail(h, XV_ERR_INVALID, "xv_forward: null feature/output pointer");
@@ -761,13 +782,8 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
   const xv_model_desc& d = h->desc;
   const bool split = d.precision == XV_PREC_BF16X3;
 
-  std::vector<hipEvent_t> ev;
-  int ntimes = 0;
-  if (times) {
-    ev.resize(p->steps.size() + 1);
-    for (auto& e : ev) XV_HIP(h, hipEventCreate(&e));
-    XV_HIP(h, hipEventRecord(ev[0], s));
-  }
+  const bool prof = h->profiling && h->prof_next + 2 * p->steps.size() <= h->prof_pool.size();
+  if (prof) h->prof_forwards++;
 
   for (size_t si = 0; si < p->steps.size(); ++si) {
     const PlanStep& st = p->steps[si];
@@ -776,11 +792,15 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
       return o == -2 ? feats : reinterpret_cast<const float*>(ws + o);
     };
     float* optr = st.out_off >= 0 ? reinterpret_cast<float*>(ws + st.out_off) : out;
-    const char* name = "op";
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (prof) {
+      pe0 = h->prof_pool[h->prof_next++];
+      pe1 = h->prof_pool[h->prof_next++];
+      XV_HIP(h, hipEventRecord(pe0, s));
+    }
     switch (op.kind) {
       case OP_GEMM: {
         const Layer& L = h->layers[op.layer];
-        name = L.ep[ST_AFFINE].c_str();
         GemmArgs a{};
         a.X = in_ptr(st.in0_off);
         a.ldx = op.in0 == 0 ? feat_ld : L.cin;
@@ -801,13 +821,11 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         break;
       }
       case OP_STAT_POOL: {
-        name = "stat_pool";
         const Value& vi = h->values[op.in0];
         XV_HIP(h, launch_stat_pool(in_ptr(st.in0_off), vi.cols, vi.cols, off, B, vi.ctx, optr, 2 * vi.cols, s));
         break;
       }
       case OP_ATT_SCORES: {
-        name = "att_scores";
         const Value& vi = h->values[op.in0];
         const float scale = d.att_use_scale ? 1.0f / std::sqrt((float)h->att_dk_h) : 1.0f;   // model/pooling.py:193-194
         XV_HIP(h, launch_att_scores(in_ptr(st.in0_off), vi.cols, st.rows_in, static_cast<const float*>(h->query.p),
@@ -816,21 +834,18 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         break;
       }
       case OP_ATT_SOFTMAX: {
-        name = "att_softmax";
         float* sc = reinterpret_cast<float*>(ws + st.out_off);
         XV_HIP(h, launch_att_softmax(sc, d.att_num_heads, off, B, 14, s));
         if (st.to_out) XV_HIP(h, launch_att_weights_out(sc, d.att_num_heads, off, B, 14, out, s));
         break;
       }
       case OP_ATT_POOL: {
-        name = "att_pool";
         const Value& vv = h->values[op.in0];
         XV_HIP(h, launch_att_pool(in_ptr(st.in0_off), vv.cols, vv.cols, in_ptr(st.in1_off), d.att_num_heads,
                                   d.att_split_value, off, B, vv.ctx, optr, h->pool_dim, s));
         break;
       }
       case OP_AFFINE_ACT: {
-        name = "att_post";
         const int n = h->pool_dim;
         const float* vec = static_cast<const float*>(h->post_vec.p);
         const int a = st.stage >= 2 ? act_of(d) : ACT_NONE;
@@ -839,29 +854,16 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         break;
       }
       case OP_L2_SCALE: {
-        name = "l2_scale";
         XV_HIP(h, launch_l2_scale(in_ptr(st.in0_off), B, h->values[op.out].cols, d.feature_scaling_factor, optr, s));
         break;
       }
       default:
         return fail(h, XV_ERR_STATE, "unknown op kind %d", op.kind);
     }
-    if (times) {
-      XV_HIP(h, hipEventRecord(ev[si + 1], s));
-      if (ntimes < max_times) {
-        xv_kernel_time& t = times[ntimes++];
-        memset(&t, 0, sizeof(t));
-        snprintf(t.name, sizeof(t.name), "%s", name);
-        t.flops = st.flops;
-        t.bytes = st.bytes;
-      }
+    if (prof) {
+      XV_HIP(h, hipEventRecord(pe1, s));
+      h->prof_recs.push_back({pe0, pe1, p, (int)si});
     }
-  }
-  if (times) {
-    XV_HIP(h, hipEventSynchronize(ev.back()));
-    for (int i = 0; i < ntimes; ++i) XV_HIP(h, hipEventElapsedTime(&times[i].ms, ev[i], ev[i + 1]));
-    for (auto& e : ev) (void)hipEventDestroy(e);
-    return ntimes;
   }
   return XV_OK;
 }
@@ -869,15 +871,61 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
 int xv_forward(xv_handle* h, const xv_plan* p, const float* feats_dev, int feat_ld, float* out_dev, int64_t out_capacity,
                void* workspace, int64_t workspace_bytes, void* stream) {
   return run_plan(h, p, feats_dev, feat_ld, out_dev, out_capacity, workspace, workspace_bytes,
-                  static_cast<hipStream_t>(stream), nullptr, 0);
+                  static_cast<hipStream_t>(stream));
 }
 
-int xv_forward_timed(xv_handle* h, const xv_plan* p, const float* feats_dev, int feat_ld, float* out_dev,
-                     int64_t out_capacity, void* workspace, int64_t workspace_bytes, void* stream,
-                     xv_kernel_time* entries, int max_entries) {
-  if (!entries || max_entries < 1) return fail(h, XV_ERR_INVALID, "xv_forward_timed: no entry buffer");
-  return run_plan(h, p, feats_dev, feat_ld, out_dev, out_capacity, workspace, workspace_bytes,
-                  static_cast<hipStream_t>(stream), entries, max_entries);
+int xv_profile_begin(xv_handle* h, int max_events) {
+  if (!h) return fail(nullptr, XV_ERR_INVALID, "xv_profile_begin: null handle");
+  if (max_events < 2) return fail(h, XV_ERR_INVALID, "xv_profile_begin: max_events < 2");
+  DeviceGuard g(h->device);
+  while ((int)h->prof_pool.size() < max_events) {
+    hipEvent_t e;
+    XV_HIP(h, hipEventCreate(&e));
+    h->prof_pool.push_back(e);
+  }
+  h->prof_next = 0;
+  h->prof_recs.clear();
+  h->prof_forwards = 0;
+  h->profiling = true;
+  return XV_OK;
+}
+
+int xv_profile_end(xv_handle* h, xv_kernel_time* entries, int max_entries, int* n_forwards) {
+  if (!h) return fail(nullptr, XV_ERR_INVALID, "xv_profile_end: null handle");
+  if (!h->profiling) return fail(h, XV_ERR_STATE, "xv_profile_end without xv_profile_begin");
+  h->profiling = false;
+  if (!entries || max_entries < 1) return fail(h, XV_ERR_INVALID, "xv_profile_end: no entry buffer");
+  DeviceGuard g(h->device);
+  int n = 0;
+  std::vector<int> count;
+  for (const auto& r : h->prof_recs) {
+    XV_HIP(h, hipEventSynchronize(r.e1));
+    float ms = 0.f;
+    XV_HIP(h, hipEventElapsedTime(&ms, r.e0, r.e1));
+    const PlanStep& st = r.plan->steps[r.step];
+    const char* name = step_name(h, st);
+    int i = 0;
+    for (; i < n; ++i)
+      if (strncmp(entries[i].name, name, sizeof(entries[i].name) - 1) == 0 && entries[i].flops == st.flops) break;
+    if (i == n) {
+      if (n >= max_entries) continue;
+      memset(&entries[n], 0, sizeof(xv_kernel_time));
+      snprintf(entries[n].name, sizeof(entries[n].name), "%s", name);
+      entries[n].flops = st.flops;
+      entries[n].bytes = st.bytes;
+      count.push_back(0);
+      ++n;
+    }
+    entries[i].ms += ms;
+    count[i]++;
+  }
+  for (int i = 0; i < n; ++i) {
+    entries[i].launches = count[i];
+    if (count[i] > 0) entries[i].ms /= (float)count[i];
+  }
+  if (n_forwards) *n_forwards = h->prof_forwards;
+  h->prof_recs.clear();
+  return n;
 }
 
 void xv_destroy(xv_handle* h) {
@@ -887,6 +935,7 @@ void xv_destroy(xv_handle* h) {
     for (auto& L : h->layers) { L.wt.release(); L.whi.release(); L.wlo.release(); L.vec.release(); }
     h->query.release();
     h->post_vec.release();
+    for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   }
   delete h;
 }

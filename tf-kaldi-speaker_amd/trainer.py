@@ -213,11 +213,11 @@ class Trainer(object):
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda:%d" % self._device_index)
         return self._ws
 
-    def predict_packed(self, feats_dev, offsets, node=None, timed=False):
+    def predict_packed(self, feats_dev, offsets, node=None, out=None):
         """Device-resident entry: `feats_dev` is a float32 CUDA tensor [total_frames, ld] holding
         the utterances back to back, `offsets` the B+1 frame offsets.  Returns a CUDA tensor
         [B, E] (segment-level node) or [total_out_frames, E] (frame-level node), enqueued on
-        the current stream.  With timed=True returns (out, [(kernel, ms, flops, bytes), ...])."""
+        the current stream (`out` may be a preallocated result tensor)."""
         if not self.is_loaded:
             self._lazy_load()
         torch = self._torch
@@ -230,16 +230,29 @@ class Trainer(object):
             raise ValueError("features have %d columns, the network needs %d" % (feats_dev.shape[1], self.dim))
         plan, info = self._plan(offsets, node)
         ws = self._workspace(info.workspace_bytes + 256)
-        out = torch.empty((int(info.out_rows), int(info.out_cols)), dtype=torch.float32, device=feats_dev.device)
+        if out is None:
+            out = torch.empty((int(info.out_rows), int(info.out_cols)), dtype=torch.float32, device=feats_dev.device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
         stream = torch.cuda.current_stream(self._device_index).cuda_stream
         args = (self._h, plan, C.c_void_p(feats_dev.data_ptr()), int(feats_dev.shape[1]),
                 C.c_void_p(out.data_ptr()), out.numel(), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream))
-        if not timed:
-            _lib.check(self._lib.xv_forward(*args), self._h)
-            return out
+        _lib.check(self._lib.xv_forward(*args), self._h)
+        return out
+
+    def profile_begin(self, max_events=4096):
+        """Start per-kernel hipEvent timing of the following predict calls (bench.py)."""
+        if not self.is_loaded:
+            self._lazy_load()
+        _lib.check(self._lib.xv_profile_begin(self._h, int(max_events)), self._h)
+
+    def profile_end(self):
+        """-> (records, n_forwards); records: dicts name/ms/launches/flops/bytes per kernel."""
         ent = (_lib.KernelTime * 64)()
-        n = _lib.check(self._lib.xv_forward_timed(*(args + (ent, 64))), self._h)
-        return out, [(ent[i].name.decode(), float(ent[i].ms), int(ent[i].flops), int(ent[i].bytes)) for i in range(n)]
+        nf = C.c_int(0)
+        n = _lib.check(self._lib.xv_profile_end(self._h, ent, 64, C.byref(nf)), self._h)
+        recs = [dict(name=ent[i].name.decode(), ms=float(ent[i].ms), launches=int(ent[i].launches),
+                     flops=int(ent[i].flops), bytes=int(ent[i].bytes)) for i in range(n)]
+        return recs, int(nf.value)
 
     def plan_info(self, offsets, node=None):
         if not self.is_loaded:
