@@ -1,0 +1,136 @@
+"""CPU: host-side logic that needs no GPU -- Params, model dir contract, extract.py driver
+behaviour (skip / chunk / weight / normalise / order) against oracle.ref_numpy.extract_utterance,
+and the C-ABI library's exported symbols."""
+import ctypes
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import ref_numpy
+from tf_kaldi_speaker_amd import extract, kaldi_io, model_io, synth
+from tf_kaldi_speaker_amd.params import Params
+
+
+def _fake_embed(utts):
+    """Deterministic stand-in for the network: depends on content and length."""
+    return np.stack([np.concatenate([u.mean(0), u.std(0) + 0.01 * u.shape[0]]) for u in utts])
+
+
+def _fake_predict(x):
+    x = np.asarray(x)
+    return _fake_embed(list(x)) if x.ndim == 3 else _fake_embed([x])[0]
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+@pytest.mark.parametrize("chunk", [40, 41, 10000])
+def test_extract_stream_matches_reference_driver_semantics(normalize, chunk):
+    """egs/voxceleb/v1/nnet/lib/extract.py:64-93 incl. S=40 chunking cases T in {39,40,41,61,100}."""
+    lens = [39, 40, 41, 61, 100, 24, 25, 200]
+    items = [("utt%d" % i, u) for i, u in enumerate(synth.synth_features(len(lens), lens, 5, seed=1))]
+    out = []
+    done, skipped = extract.extract_stream(_fake_embed, iter(items), lambda k, v: out.append((k, v)),
+                                           min_chunk_size=25, chunk_size=chunk, normalize=normalize, batch_frames=150)
+    expect = []
+    for k, f in items:
+        e = ref_numpy.extract_utterance(f, _fake_predict, 25, chunk, normalize)
+        if e is not None:
+            expect.append((k, e))
+    assert skipped == 1 and done == len(expect)
+    assert [k for k, _ in out] == [k for k, _ in expect]            # input order kept across batches
+    for (_, a), (_, b) in zip(out, expect):
+        assert a.dtype == np.float32
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_split_chunks_formula():
+    """num_chunks = ceil((T-S)/(S//2)) + 1, starts i*(S//2), last length T-start (extract.py:70-76)."""
+    assert extract.split_chunks(41, 40) == [(0, 40), (20, 21)]
+    assert extract.split_chunks(100, 40) == [(0, 40), (20, 40), (40, 40), (60, 40)]
+    assert extract.split_chunks(101, 40) == [(0, 40), (20, 40), (40, 40), (60, 40), (80, 21)]
+    assert extract.split_chunks(61, 41) == [(0, 41), (20, 41)]     # odd S: hop = 20
+
+
+def test_cli_parser_keeps_reference_flags():
+    a = extract.build_parser().parse_args(["-g", "3", "-m", "50", "-s", "3000", "-n", "--node", "output", "m", "ark:in", "ark:out"])
+    assert (a.gpu, a.min_chunk_size, a.chunk_size, a.normalize, a.node) == (3, 50, 3000, True, "output")
+    assert (a.model_dir, a.rspecifier, a.wspecifier) == ("m", "ark:in", "ark:out")
+    d = extract.build_parser().parse_args(["m", "r", "w"])
+    assert (d.gpu, d.min_chunk_size, d.chunk_size, d.normalize, d.node) == (-1, 25, 10000, False, "")
+
+
+def test_params_attribute_and_dict_access(tmp_path):
+    """misc/utils.py:13-41."""
+    path = tmp_path / "c.json"
+    path.write_text(json.dumps({"network_type": "tdnn", "embedding_node": "tdnn6_dense"}))
+    p = Params(str(path))
+    assert p.network_type == "tdnn" and "pooling_type" not in p.dict
+    p.embedding_node = "output"
+    assert p.dict["embedding_node"] == "output"
+    p.dict["num_nodes_pooling_layer"] = 1500
+    assert p.num_nodes_pooling_layer == 1500
+    p.save(str(tmp_path / "d.json"))
+    assert Params(str(tmp_path / "d.json")).embedding_node == "output"
+
+
+def test_model_dir_round_trip(tmp_path):
+    p = dict(synth.TDNN_STAT_PARAMS)
+    p["num_nodes_pooling_layer"] = 8
+    w = synth.synth_weights(p, 5, seed=1, channels=16)
+    nnet = model_io.save_model(str(tmp_path / "exp"), p, 5, w, step=420000)
+    assert sorted(os.listdir(nnet)) == ["checkpoint", "config.json", "feature_dim", "model-420000.npz"]
+    w2, step = model_io.load_weights(nnet)
+    assert step == 420000 and set(w2) == set(w)
+    for k in w:
+        np.testing.assert_array_equal(w[k], w2[k])
+    assert model_io.load_weights(str(tmp_path)) == (None, None)
+
+
+def test_synth_weights_cover_reference_variable_names():
+    w = synth.synth_weights(dict(synth.TDNN_ATT_PARAMS, network_relu_type="prelu", att_apply_nonlinear=True), 30, seed=0)
+    assert w["tdnn/tdnn1_conv/kernel"].shape == (1, 5, 30, 512)
+    assert w["tdnn/tdnn3_conv/kernel"].shape == (1, 7, 512, 512)
+    assert w["tdnn/tdnn5_dense/kernel"].shape == (512, 1500)
+    assert w["tdnn/tdnn6_dense/kernel"].shape == (3000, 512)
+    assert w["tdnn/attention/att_key0/att_key0_dense/kernel"].shape == (512, 1500)
+    assert w["tdnn/attention/att_key1/att_key1_dense/kernel"].shape == (1500, 1500)
+    assert "tdnn/attention/att_key1/att_key1_bn/gamma" not in w          # type 1 = affine + relu
+    assert w["tdnn/attention/query"].shape == (1, 1500)
+    assert w["tdnn/tdnn4_relu/alpha"].shape == (512,)
+    assert w["tdnn/attention/att_post_bn/gamma"].shape == (3000,)
+
+
+def test_c_abi_library_exports_every_declared_symbol(repo_root):
+    """The shared library loads on a GPU-less box and exports what include/xvec_hip.h declares."""
+    import __graft_entry__ as g
+    g.build()
+    hdr = open(os.path.join(repo_root, "include", "xvec_hip.h")).read()
+    declared = set(re.findall(r"\b(xv_[a-z_]+)\s*\(", hdr))
+    from tf_kaldi_speaker_amd import _lib
+    assert declared == set(_lib.EXPORTS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.xv_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.xv_version()
+    assert ctypes.sizeof(_lib.ModelDesc) == 4 * (26 + 2 * (_lib.XV_MAX_ATT_LAYERS - 1))
+
+
+def test_trainer_refuses_unsupported_graphs_and_missing_gpu():
+    from tf_kaldi_speaker_amd.trainer import Trainer
+    with pytest.raises(NotImplementedError):
+        Trainer(Params(**dict(synth.TDNN_STAT_PARAMS, network_type="resnet_18")), None, 40)
+    with pytest.raises(NotImplementedError):
+        Trainer(Params(**dict(synth.TDNN_STAT_PARAMS, network_type="nonsense")), None, 30)
+    tr = Trainer(Params(**dict(synth.TDNN_STAT_PARAMS, pooling_type="ghost_vlad")), None, 30)
+    with pytest.raises(NotImplementedError):
+        tr.build("predict")
+    import torch
+    if not torch.cuda.is_available():
+        tr = Trainer(Params(**dict(synth.TDNN_STAT_PARAMS)), None, 30)
+        tr.build("predict")
+        with pytest.raises(RuntimeError):                       # no silent CPU fallback
+            tr.load_weights(synth.synth_weights(synth.TDNN_STAT_PARAMS, 30, channels=8))

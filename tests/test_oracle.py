@@ -1,0 +1,110 @@
+"""CPU: the oracle against the reference's own pins (tests/golden/, made by make_golden.py from
+/root/reference/model/test_utils.py) and the two restatements against each other.
+
+The TDNN layers themselves are **parity unpinned** (the reference holds no golden vector for
+them and TensorFlow is not installed): for those the check is numpy-f64 vs torch-f32
+(independent formulations: shifted matmuls vs F.conv1d)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_numpy, ref_torch
+from tf_kaldi_speaker_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "attention_*.npz"))))
+def test_attention_core_matches_reference_numpy_twin(path):
+    """model/test_utils.py:321-392 compute_self_attention (fixtures attention_*.npz)."""
+    z = np.load(path)
+    split = bool(z["split"])
+    att, w = ref_numpy.attention_core(z["value"], z["key"], z["query"], int(z["heads"]), split, split, bool(z["use_scale"]))
+    np.testing.assert_allclose(att, z["att"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(w.sum(-1), 1.0, rtol=1e-12)
+
+
+def test_statistics_pooling_matches_reference_mean_std():
+    """model/test_utils.py:1114 (np.mean || np.std) + the 1e-12 variance floor of pooling.py:46-48."""
+    z = np.load(os.path.join(GOLD, "stat_pool.npz"))
+    got = ref_numpy.statistics_pooling(z["x"])
+    ref = z["mean_std"].copy()
+    c = z["x"].shape[2]
+    ref[:, c:] = np.maximum(ref[:, c:], 1e-6)          # sqrt(1e-12): reference floors the variance
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-13)
+    assert np.all(got[:, c + 5] == 1e-6)                # the constant channel hits the floor
+
+
+def _small_params(pooling, **kw):
+    p = dict(synth.TDNN_ATT_PARAMS if pooling == "self_attention" else synth.TDNN_STAT_PARAMS)
+    p["num_nodes_pooling_layer"] = 40
+    p["num_nodes_last_layer"] = 24
+    if pooling == "self_attention":
+        p["att_key_num_nodes"] = [20, 16]
+    p.update(kw)
+    return p
+
+
+@pytest.mark.parametrize("pooling,kw", [
+    ("statistics_pooling", {}),
+    ("statistics_pooling", {"network_relu_type": "prelu", "last_layer_linear": True}),
+    ("statistics_pooling", {"network_relu_type": "lrelu", "last_layer_no_bn": True, "feature_norm": True,
+                            "feature_scaling_factor": 30.0}),
+    ("self_attention", {}),
+    ("self_attention", {"att_num_heads": 4, "att_apply_nonlinear": True, "network_relu_type": "prelu"}),
+    ("self_attention", {"att_num_heads": 2, "att_split_key": False, "att_split_value": False, "att_key_network_type": 3,
+                        "att_value_num_nodes": [12], "att_value_network_type": 2, "att_use_scale": False}),
+])
+def test_numpy_and_torch_restatements_agree(pooling, kw):
+    p = _small_params(pooling, **kw)
+    w = synth.synth_weights(p, 7, seed=3, channels=32)
+    if "tdnn/attention/query" in w:
+        w["tdnn/attention/query"] = w["tdnn/attention/query"] * 20.0    # non-uniform attention
+    feats = np.stack(synth.synth_features(3, 33, 7, seed=5))
+    _, ep = ref_numpy.entire_network(feats, w, p)
+    ep_t = ref_torch.TorchTdnn(w, p).forward(feats)
+    assert list(ep.keys()) == list(ep_t.keys())
+    for k in ep:
+        a, b = ep[k], ep_t[k].numpy().astype(np.float64)
+        assert a.shape == b.shape, k
+        err = np.linalg.norm(a - b) / max(np.linalg.norm(a), 1e-30)
+        assert err < 2e-6, (k, err)
+
+
+def test_full_size_tdnn_restatements_agree():
+    p = dict(synth.TDNN_STAT_PARAMS)
+    w = synth.synth_weights(p, 30, seed=0)
+    feats = np.stack(synth.synth_features(1, 60, 30, seed=1))
+    a = ref_numpy.predict(feats, w, p, 30)
+    b = ref_torch.TorchTdnn(w, p).predict(feats, 30)
+    assert a.shape == (1, 512)
+    assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-6
+
+
+def test_conv_is_valid_cross_correlation_no_flip():
+    """y[t,o] = sum_k sum_c x[t+k,c] W[0,k,c,o] + b[o] (model/tdnn.py:42-47, TF 'valid', stride 1)."""
+    rs = np.random.RandomState(0)
+    x = rs.standard_normal((1, 9, 3))
+    k = rs.standard_normal((1, 5, 3, 4))
+    b = rs.standard_normal(4)
+    y = ref_numpy.conv_valid(x, k, b)
+    assert y.shape == (1, 5, 4)
+    for t in range(5):
+        for o in range(4):
+            ref = sum(x[0, t + j, c] * k[0, j, c, o] for j in range(5) for c in range(3)) + b[o]
+            assert abs(y[0, t, o] - ref) < 1e-12
+
+
+def test_predict_rank_handling_and_dim_truncation():
+    """model/trainer.py:897-912."""
+    p = _small_params("statistics_pooling")
+    w = synth.synth_weights(p, 7, seed=3, channels=32)
+    f = synth.synth_features(2, 20, 9, seed=2)
+    e3 = ref_numpy.predict(np.stack(f), w, p, 7)
+    e2 = ref_numpy.predict(f[1], w, p, 7)
+    assert e3.shape == (2, 32) and e2.shape == (32,)
+    np.testing.assert_allclose(e2, e3[1], rtol=1e-12)
+    np.testing.assert_allclose(ref_numpy.predict(f[1][:, :7], w, p, 7), e2, rtol=1e-12)
+    assert ref_numpy.predict(f[0], w, p, 7, node="tdnn3_relu").shape == (6, 32)

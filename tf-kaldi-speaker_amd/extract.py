@@ -1,0 +1,162 @@
+"""Embedding extraction driver: Kaldi matrix ark in -> x-vector ark out.
+
+Same command line and per-utterance behaviour as the reference driver
+egs/voxceleb/v1/nnet/lib/extract.py (argparse :11-24; model dir contract :42-55; scp
+rspecifier refused :59-61; min-length skip :65-67; long-utterance half-overlap chunking and
+length-weighted average :68-86; optional L2 normalisation :84-85,91-92; vector ark out :93):
+
+    extract.py [-g GPU] [-m MIN] [-s CHUNK] [-n] [--node NODE] model_dir rspecifier wspecifier
+
+What differs is how the device is fed: instead of one sess.run per utterance (extract.py:89)
+utterances (and the chunks of long ones) are packed back to back into ragged batches of up
+to --batch-frames frames and sent through `Trainer.predict_list` in one launch sequence;
+results are written in input order, so the output ark is the one the reference would write.
+"""
+import argparse
+import logging
+import os
+import sys
+
+import numpy as np
+
+from .kaldi_io import open_or_fd, read_mat_ark, write_vec_flt
+from .params import Params
+
+log = logging.getLogger("xvec.extract")
+
+
+def build_parser():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-g", "--gpu", type=int, default=-1,
+                        help="The GPU id.  -1 (the reference's 'GPU disabled') selects LOCAL_RANK or device 0: "
+                             "this implementation has no CPU path.")
+    parser.add_argument("-m", "--min-chunk-size", type=int, default=25,
+                        help="The minimum length of the segments. Any segment shorted than this value will be ignored.")
+    parser.add_argument("-s", "--chunk-size", type=int, default=10000,
+                        help="The length of the segments used to extract the embeddings. Segments longer than this value "
+                             "will be splited before extraction. Then the splited embeddings will be averaged to get the "
+                             "final embedding. L2 normalizaion will be applied before the averaging if specified.")
+    parser.add_argument("-n", "--normalize", action="store_true", help="Normalize the embedding before averaging and output.")
+    parser.add_argument("--node", type=str, default="", help="The node to output the embeddings.")
+    parser.add_argument("--batch-frames", type=int, default=76800,
+                        help="Frames packed into one device batch (extension; 76800 = 256 utterances x 300 frames).")
+    parser.add_argument("--precision", type=str, default="", help="f32 | bf16x3 (extension; default: library default)")
+    parser.add_argument("model_dir", type=str, help="The model directory.")
+    parser.add_argument("rspecifier", type=str, help="Kaldi feature rspecifier (or ark file).")
+    parser.add_argument("wspecifier", type=str, help="Kaldi output wspecifier (or ark file).")
+    return parser
+
+
+def split_chunks(num_frames, chunk_size):
+    """(start, length) of the pieces of an utterance longer than chunk_size: chunks of
+    chunk_size at hop chunk_size//2, the last one shorter (extract.py:70-77; `chunk_size / 2`
+    there is Python-2 integer division)."""
+    half = chunk_size // 2
+    num_chunks = int(np.ceil(float(num_frames - chunk_size) / half)) + 1
+    pieces = []
+    for i in range(num_chunks):
+        start = i * half
+        this = chunk_size if num_frames - start > chunk_size else num_frames - start
+        pieces.append((start, this))
+    return pieces
+
+
+def combine_chunks(embeddings, lengths, normalize):
+    """extract.py:83-86: optional per-chunk L2 normalisation, then length-weighted mean."""
+    embeddings = np.asarray(embeddings)
+    lengths = np.expand_dims(np.asarray(lengths), axis=1)
+    if normalize:
+        embeddings = embeddings / np.sqrt(np.sum(np.square(embeddings), axis=1, keepdims=True))
+    return np.sum(embeddings * lengths, axis=0) / np.sum(lengths)
+
+
+def extract_stream(embed_fn, items, write_fn, min_chunk_size=25, chunk_size=10000, normalize=False,
+                   batch_frames=76800):
+    """Core loop.  `items` yields (key, [T,d] matrix); `embed_fn(list of [T_i,d])` returns an
+    [n,E] array; `write_fn(key, vector)` is called once per kept utterance, in input order.
+    Returns (#written, #skipped)."""
+    pending = []          # (key, [(piece_index...)], lengths or None)
+    pieces = []           # feature pieces of the current batch
+    frames = 0
+    done = skipped = 0
+
+    def flush():
+        nonlocal pieces, pending, frames, done
+        if not pending:
+            return
+        emb = np.asarray(embed_fn(pieces))
+        for key, idx, lengths in pending:
+            if lengths is None:
+                e = emb[idx[0]]
+            else:
+                e = combine_chunks(emb[idx], lengths, normalize)
+            if normalize:
+                e = e / np.sqrt(np.sum(np.square(e)))                      # extract.py:91-92
+            write_fn(key, np.asarray(e, dtype=np.float32))
+            done += 1
+        pieces, pending, frames = [], [], 0
+
+    for key, feature in items:
+        t = feature.shape[0]
+        if t < min_chunk_size:
+            log.info("[INFO] Key %s length too short, %d < %d, skip." % (key, t, min_chunk_size))
+            skipped += 1
+            continue
+        if t > chunk_size:
+            parts = split_chunks(t, chunk_size)
+            log.info("[INFO] Key %s length %d > %d, split to %d segments." % (key, t, chunk_size, len(parts)))
+            idx = []
+            for start, length in parts:
+                idx.append(len(pieces))
+                pieces.append(feature[start:start + length])
+            pending.append((key, idx, [p[1] for p in parts]))
+        else:
+            log.info("[INFO] Key %s length %d." % (key, t))
+            pending.append((key, [len(pieces)], None))
+            pieces.append(feature)
+        frames += t
+        if frames >= batch_frames:
+            flush()
+    flush()
+    return done, skipped
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format="%(message)s")
+    nnet_dir = os.path.join(args.model_dir, "nnet")
+    config_json = os.path.join(args.model_dir, "nnet/config.json")
+    if not os.path.isfile(config_json):
+        sys.exit("Cannot find params.json in %s" % config_json)
+    params = Params(config_json)
+    if len(args.node) != 0:                                  # extract.py:50-51
+        params.embedding_node = args.node
+    log.info("Extract embedding from %s" % params.embedding_node)
+    with open(os.path.join(nnet_dir, "feature_dim"), "r") as f:
+        dim = int(f.readline().strip())
+
+    from .trainer import Trainer
+    device = args.gpu if args.gpu >= 0 else None
+    trainer = Trainer(params, args.model_dir, dim, single_cpu=True, device=device, precision=args.precision or None)
+    trainer.build("predict")
+
+    if args.rspecifier.rsplit(".", 1)[-1] == "scp":          # extract.py:59-61
+        sys.exit("The rspecifier must be ark or input pipe")
+
+    fp_out = open_or_fd(args.wspecifier, "wb")
+    done, skipped = extract_stream(
+        trainer.predict_list, read_mat_ark(args.rspecifier),
+        lambda key, vec: write_vec_flt(fp_out, vec, key=key),
+        min_chunk_size=args.min_chunk_size, chunk_size=args.chunk_size, normalize=args.normalize,
+        batch_frames=args.batch_frames)
+    fp_out.close()
+    proc = getattr(fp_out, "_xv_proc", None)
+    if proc is not None:
+        proc.wait()
+    trainer.close()
+    log.info("Extracted %d embeddings (%d utterances skipped)." % (done, skipped))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

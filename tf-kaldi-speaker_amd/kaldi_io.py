@@ -248,21 +248,23 @@ _U16 = 1.52590218966964e-05      # 1/65535, the constant the reference uses (:10
 
 
 def _decode_cm1(s):
-    """'CM ' compressed matrix (per-column percentile headers + column-major u8), decoded
-    as the reference does (dataset/kaldi_io.py:1071-1115), in one vectorised pass."""
+    """'CM ' compressed matrix (per-column percentile headers + column-major u8): the
+    piecewise-linear decode of dataset/kaldi_io.py:1071-1115, in one vectorised pass.
+
+    Arithmetic is done in float64 and rounded to float32 once, which is what Kaldi's
+    CompressedMatrix does (float * double constant) and what the reference's expressions did
+    under the NumPy 1.x it was written for (np.float32 scalar * python float -> float64).
+    Under NumPy >= 2 (NEP 50) the same reference source keeps float32 intermediates and can
+    differ from this by one float32 ulp; tests/test_kaldi_io.py allows exactly that."""
     gmin, grange, rows, cols = struct.unpack('<ffii', s.read_exact(16))
-    gmin = np.float32(gmin)
-    grange = np.float32(grange)
     hdr = np.frombuffer(s.read_exact(cols * 8), dtype='<u2').reshape(cols, 4)
     data = np.frombuffer(s.read_exact(cols * rows), dtype=np.uint8).reshape(cols, rows)
-    # uint16_to_float: np.float32(min + range * 1.5259e-05 * value) -- python-float arithmetic
-    # on float32 scalars promotes to float64 before the final cast; mirror that.
-    p = (np.float64(gmin) + np.float64(grange) * _U16 * hdr.astype(np.float64)).astype(np.float32)
+    p = (np.float64(gmin) + np.float64(grange) * _U16 * hdr.astype(np.float64)).astype(np.float32).astype(np.float64)
     p0, p25, p75, p100 = (p[:, i:i + 1] for i in range(4))
-    d = data.astype(np.float32)
-    lo = p0 + (p25 - p0) / np.float32(64.) * d
-    mid = p25 + (p75 - p25) / np.float32(128.) * (d - np.float32(64.))
-    hi = p75 + (p100 - p75) / np.float32(63.) * (d - np.float32(192.))
+    d = data.astype(np.float64)
+    lo = p0 + (p25 - p0) / 64. * d
+    mid = p25 + (p75 - p25) / 128. * (d - 64.)
+    hi = p75 + (p100 - p75) / 63. * (d - 192.)
     out = np.where(data <= 64, lo, np.where(data <= 192, mid, hi)).astype(np.float32)
     return np.ascontiguousarray(out.T)
 

@@ -301,6 +301,34 @@ class Trainer(object):
             emb = np.squeeze(emb, axis=0)
         return emb
 
+    def predict_list(self, utterances, node=None):
+        """Ragged batch: a list of [T_i, d] matrices packed back to back and run as ONE launch
+        sequence (what the reference does with one sess.run per utterance, extract.py:89).
+        Returns [n, E] for a segment-level node, a list of [T_i', E] for a frame-level node."""
+        if not self.is_loaded:
+            self._lazy_load()
+        torch = self._torch
+        node = node or self.embeddings
+        lens = [int(u.shape[0]) for u in utterances]
+        d = int(utterances[0].shape[1])
+        if d < self.dim:
+            raise ValueError("features have %d columns, the network needs %d" % (d, self.dim))
+        host = np.concatenate([np.asarray(u, dtype=np.float32) for u in utterances], axis=0)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        with torch.cuda.device(self._device_index):
+            dev = torch.from_numpy(np.ascontiguousarray(host)).to("cuda:%d" % self._device_index)
+            out = self.predict_packed(dev, offsets, node)
+            _, info = self._plan(offsets, node)
+            emb = out.cpu().numpy()
+        if node == "attention_weights" or not info.frame_level:
+            return emb
+        ctx = (int(offsets[-1]) - emb.shape[0]) // len(lens)
+        res, pos = [], 0
+        for t in lens:
+            res.append(emb[pos:pos + t - ctx])
+            pos += t - ctx
+        return res
+
     # ------------------------------------------------------------------ teardown
     def _release(self):
         if self._lib is not None:
