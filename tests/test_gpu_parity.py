@@ -37,31 +37,104 @@ def stat_model():
     return params, weights
 
 
-def test_every_endpoint_statistics_pooling(stat_model):
+PRECISIONS = ["f32", "bf16x3"]
+_report = []
+
+
+def _note(test, precision, name, err):
+    _report.append("%-28s %-7s %-28s %.3e" % (test, precision, name, err))
+
+
+def teardown_module(module):
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_report.txt", "w") as f:
+        f.write("\n".join(_report) + "\n")
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_every_endpoint_statistics_pooling(stat_model, precision):
     """All endpoints of model/tdnn.py:36-181 on a [3,41,30] batch."""
     from tf_kaldi_speaker_amd import synth
     params, weights = stat_model
     feats = np.stack(synth.synth_features(3, 41, 30, seed=11))
     _, ep = ref_numpy.entire_network(feats, weights, params)
-    tr, _ = _trainer(params, weights, 30)
+    tr, _ = _trainer(params, weights, 30, precision)
     for name, ref in ep.items():
         tr.set_embedding(name)
         got = tr.predict(feats)
         assert got.shape == ref.shape, (name, got.shape, ref.shape)
         err = _rel(got, ref)
+        _note("endpoints_stat", precision, name, err)
         assert err <= TOL, (name, err)
     tr.close()
 
 
-def test_xvector_300_frames(stat_model):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_every_endpoint_self_attention(precision):
+    """model/pooling.py:55-240 with the shipped attention config
+    (egs/voxceleb/v1/nnet_conf/tdnn_softmax_1e-2_tdnn4_att_pretrain.json:15-28)."""
+    from tf_kaldi_speaker_amd import synth
+    params = dict(synth.TDNN_ATT_PARAMS)
+    weights = synth.synth_weights(params, 30, seed=2)
+    weights["tdnn/attention/query"] = weights["tdnn/attention/query"] * 1000.0   # peaky attention
+    feats = np.stack(synth.synth_features(2, 52, 30, seed=12))
+    _, ep = ref_numpy.entire_network(feats, weights, params)
+    assert ep["attention_weights"].max() > 5.0 / 38                # really non-uniform (uniform = 1/38)
+    tr, _ = _trainer(params, weights, 30, precision)
+    for name, ref in ep.items():
+        if name.startswith("tdnn") and name[4] in "123" or name in ("tdnn4_dense", "tdnn4_bn", "tdnn5_dense", "tdnn5_bn"):
+            continue                                               # covered by the statistics test
+        tr.set_embedding(name)
+        got = tr.predict(feats)
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        err = _rel(got, ref)
+        _note("endpoints_att", precision, name, err)
+        assert err <= TOL, (name, err)
+    tr.close()
+
+
+@pytest.mark.parametrize("kw", [
+    {"att_num_heads": 4, "att_apply_nonlinear": True, "network_relu_type": "prelu"},
+    {"att_num_heads": 3, "att_split_key": False, "att_split_value": False, "att_key_network_type": 3,
+     "att_key_num_nodes": [96], "att_value_num_nodes": [64, 48], "att_value_network_type": 2, "att_use_scale": False,
+     "att_key_input": "tdnn5_relu", "att_value_input": "tdnn4_relu", "network_relu_type": "lrelu",
+     "last_layer_no_bn": True, "feature_norm": True, "feature_scaling_factor": 12.0},
+    {"att_num_heads": 2, "att_key_num_nodes": [64, 32, 16], "att_key_network_type": 0, "last_layer_linear": True},
+])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_attention_variants_small(kw, precision):
+    """Multi-head / split / non-split / tanh / post-BN variants on a shrunk graph (channels 64)."""
+    from tf_kaldi_speaker_amd import synth
+    params = dict(synth.TDNN_ATT_PARAMS, num_nodes_pooling_layer=96, num_nodes_last_layer=40)
+    params["att_key_num_nodes"] = [64, 48]
+    params.update(kw)
+    weights = synth.synth_weights(params, 23, seed=4, channels=64)
+    weights["tdnn/attention/query"] = weights["tdnn/attention/query"] * 20.0
+    feats = np.stack(synth.synth_features(3, 37, 23, seed=13))
+    _, ep = ref_numpy.entire_network(feats, weights, params)
+    tr, _ = _trainer(params, weights, 23, precision)
+    for name in ("attention_weights", "att_output_before_nonlinear", "pooling", "tdnn6_dense", "output"):
+        tr.set_embedding(name)
+        got = tr.predict(feats)
+        assert got.shape == ep[name].shape, (name, got.shape)
+        err = _rel(got, ep[name])
+        _note("att_variants", precision, name, err)
+        assert err <= TOL, (name, kw, err)
+    tr.close()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_xvector_300_frames(stat_model, precision):
     """BASELINE config 2 shape (30-dim x 300 frames), small batch, tdnn6_dense."""
     from tf_kaldi_speaker_amd import synth
     params, weights = stat_model
     feats = np.stack(synth.synth_features(4, 300, 30, seed=1234))
     ref = ref_numpy.predict(feats, weights, params, 30)
-    tr, _ = _trainer(params, weights, 30)
+    tr, _ = _trainer(params, weights, 30, precision)
     got = tr.predict(feats)
     err = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    _note("xvector_300", precision, "tdnn6_dense", err.max())
     assert err.max() <= TOL, err
     # rank-2 input squeezes (model/trainer.py:911-912); extra feature columns are dropped (:906-907)
     one = tr.predict(np.concatenate([feats[1], np.ones((300, 3), np.float32)], axis=1))
@@ -70,19 +143,21 @@ def test_xvector_300_frames(stat_model):
     tr.close()
 
 
-def test_ragged_batch_matches_per_utterance(stat_model):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_ragged_batch_matches_per_utterance(stat_model, precision):
     """Packed ragged batch (config 4 shape) == each utterance alone (oracle)."""
     import torch
     from tf_kaldi_speaker_amd import synth
     params, weights = stat_model
     lens = [15, 200, 16, 333, 25, 64, 1000, 129]
     utts = synth.synth_features(len(lens), lens, 30, seed=5)
-    tr, _ = _trainer(params, weights, 30)
+    tr, _ = _trainer(params, weights, 30, precision)
     packed = torch.from_numpy(np.concatenate(utts, axis=0)).cuda()
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     got = tr.predict_packed(packed, offsets).cpu().numpy()
     for i, u in enumerate(utts):
         ref = ref_numpy.predict(u, weights, params, 30)
+        _note("ragged", precision, "T=%d" % lens[i], _rel(got[i], ref))
         assert _rel(got[i], ref) <= TOL, (i, lens[i])
     # frame-level node on the ragged batch: packed rows in utterance order
     frames = tr.predict_packed(packed, offsets, node="tdnn3_relu").cpu().numpy()

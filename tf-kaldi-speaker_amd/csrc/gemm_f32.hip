@@ -21,32 +21,13 @@
 //    exactly like the A tile and needs no bounds checks.
 //  * XCD-aware block order: consecutive ids on one XCD (id % 8) walk the N tiles of the same M
 //    tile, so the A panel is fetched once per XCD L2.
-#include "xv_kernels.h"
+#include "xv_epilogue.h"
 
 namespace xv {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDT = BK + 4;               // padded LDS row (floats)
 constexpr int TILE_F = BM * LDT;          // floats per operand tile
-
-__device__ __forceinline__ float apply_act(float v, int act, float alpha) {
-  switch (act) {
-    case ACT_RELU: return fmaxf(v, 0.0f);
-    case ACT_LRELU: return fmaxf(v, kLreluAlpha * v);                 // tf.nn.leaky_relu
-    case ACT_PRELU: return fmaxf(v, 0.0f) + alpha * (v - fabsf(v)) * 0.5f;  // model/common.py:40-42
-    case ACT_TANH: return tanhf(v);
-    default: return v;
-  }
-}
-
-// XCD-aware bijective remap of a 1-D grid (cdna guide T1): ids congruent mod 8 share an XCD.
-__device__ __forceinline__ int xcd_remap(int id, int n) {
-  const int q = n >> 3, r = n & 7, x = id & 7, i = id >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, int nNt) {
@@ -143,29 +124,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, i
     __syncthreads();
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h
 #pragma unroll
-  for (int nj = 0; nj < 2; ++nj) {
-    const int n = n0 + wn * 64 + nj * 32 + r32;
-    const bool nok = n < p.N;
-    const float sc = nok ? p.scale[n] : 0.f;
-    const float sh = nok ? p.shift[n] : 0.f;
-    const float al = (nok && p.alpha) ? p.alpha[n] : 0.f;
+  for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m < p.M && nok) {
-          const int orow = p.rowmap ? p.rowmap[m] : m;
-          if (orow >= 0) {
-            const float v = apply_act(fmaf(acc[mi][nj][e], sc, sh), p.act, al);
-            p.Y[(int64_t)orow * p.ldy + n] = v;
-          }
-        }
-      }
-    }
-  }
+    for (int nj = 0; nj < 2; ++nj)
+      store_tile_32x32(p, acc[mi][nj], m0 + wm * 64 + mi * 32, n0 + wn * 64 + nj * 32, lane);
 }
 
 hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s) {

@@ -33,13 +33,13 @@ struct GemmArgs {
   const int32_t* rowmap;  // [M] output row or -1 (skip); nullptr = identity
   float* Y;               // fp32 output (may be nullptr when only the split planes are wanted)
   int64_t ldy;
-  // bf16x3 path: activations are carried between layers as two bf16 planes (hi + lo ~= fp32)
-  const uint16_t* Xhi;    // input planes (same indexing as X), nullptr on the fp32 path
-  const uint16_t* Xlo;
-  uint16_t* Yhi;          // output planes (same indexing as Y), nullptr when not needed
-  uint16_t* Ylo;
-  const uint16_t* Whi;    // packed weight planes [Npad][Kpad]
-  const uint16_t* Wlo;
+  // bf16x3 path: activations consumed by a split GEMM are carried in the split-blocked (SB)
+  // format of xv_epilogue.h (per row: blocks of [32 x bf16 hi | 32 x bf16 lo], 128 bytes).
+  const void* Xsb;        // SB input (bf16x3 kernel), row stride ldsbx elements (x4 bytes)
+  int64_t ldsbx;          // multiple of 32; == cin for convolutions
+  void* Ysb;              // SB output or nullptr
+  int ldsb;               // channels per SB output row incl. zero padding (multiple of 32)
+  const void* Wsb;        // packed weights in SB format [Npad][Kpad/32][128 bytes]
 };
 
 // fp32 MFMA (v_mfma_f32_32x32x2_f32) path.  aligned: ldx == cin (or K == cin), ldx % 4 == 0,
@@ -48,8 +48,6 @@ hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s);
 
 // bf16x3 split path (3x v_mfma_f32_32x32x16_bf16 per product tile).
 hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s);
-// fp32 -> (hi, lo) bf16 planes, elementwise (used for the network input of the split path)
-hipError_t launch_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, hipStream_t s);
 
 // rowmap for a valid convolution of width w over packed utterances:
 //   in_off[b] = off0[b] - b*ctx_in  (rows of utterance b in the layer's input)

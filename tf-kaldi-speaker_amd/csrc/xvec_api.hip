@@ -72,8 +72,9 @@ struct Layer {
   bool has_bn = false;
   int act = ACT_NONE;         // activation of the final stage
   // device
-  DevBuf wt;                  // fp32 [Npad][Kpad]
-  DevBuf whi, wlo;            // bf16 planes [Npad][Kpad] (bf16x3 path)
+  DevBuf wt;                  // fp32 [Npad][Kpad]                      (fp32 MFMA kernel)
+  DevBuf wsb;                 // split-blocked bf16 hi/lo [Npad][Kpad/32][128 B] (bf16x3 kernel)
+  bool use_split = false;     // this layer runs on the bf16x3 kernel
   DevBuf vec;                 // [bias | bn_scale | bn_shift | alpha | ones] each cout floats
   int Kpad = 0, Npad = 0;
   int final_stage() const { return act != ACT_NONE ? ST_ACT : (has_bn ? ST_BN : ST_AFFINE); }
@@ -148,8 +149,10 @@ struct PlanStep {
   int op = -1;
   int stage = -1;               // stage override for the target op, else the op's final stage
   bool to_out = false;          // writes the user's output buffer
-  int64_t out_off = -1;         // workspace byte offset of the output value
-  int64_t in0_off = -1, in1_off = -1;   // -2 = network input
+  int64_t out_off = -1;         // workspace byte offset of the fp32 output (-1: none / user buffer)
+  int64_t out_sb_off = -1;      // workspace byte offset of the split-blocked output (-1: none)
+  int64_t in0_off = -1, in1_off = -1;   // fp32 inputs; -2 = network input
+  int64_t in0_sb_off = -1;      // split-blocked input
   int64_t rows_in = 0, rows_out = 0;
   int M = 0;                    // GEMM rows to compute
   int rowmap = -1;              // index into plan rowmaps (conv layers)
@@ -400,25 +403,25 @@ int upload_layer(xv_handle* h, Layer& L) {
   XV_HIP(h, hipMemcpy(L.vec.p, vec.data(), vec.size() * sizeof(float), hipMemcpyHostToDevice));
 
   const size_t elems = (size_t)L.Npad * L.Kpad;
-  if (h->desc.precision == XV_PREC_F32) {
+  if (!L.use_split) {
     std::vector<float> wt(elems, 0.f);
     for (int k = 0; k < K; ++k)
       for (int n = 0; n < N; ++n) wt[(size_t)n * L.Kpad + k] = W[(size_t)k * N + n];
     XV_HIP(h, L.wt.alloc(elems * sizeof(float)));
     XV_HIP(h, hipMemcpy(L.wt.p, wt.data(), elems * sizeof(float), hipMemcpyHostToDevice));
   } else {
-    std::vector<uint16_t> hi(elems, 0), lo(elems, 0);
+    // split-blocked: row n, block kb: [32 x hi | 32 x lo] for k = 32*kb .. 32*kb+31 (xv_epilogue.h)
+    std::vector<uint16_t> sb(elems * 2, 0);
     for (int k = 0; k < K; ++k)
       for (int n = 0; n < N; ++n) {
         const float wv = W[(size_t)k * N + n];
         const uint16_t a = f32_to_bf16_rn(wv);
-        hi[(size_t)n * L.Kpad + k] = a;
-        lo[(size_t)n * L.Kpad + k] = f32_to_bf16_rn(wv - bf16_to_f32(a));
+        const size_t blk = ((size_t)n * (L.Kpad / 32) + k / 32) * 64;
+        sb[blk + (k & 31)] = a;
+        sb[blk + 32 + (k & 31)] = f32_to_bf16_rn(wv - bf16_to_f32(a));
       }
-    XV_HIP(h, L.whi.alloc(elems * 2));
-    XV_HIP(h, L.wlo.alloc(elems * 2));
-    XV_HIP(h, hipMemcpy(L.whi.p, hi.data(), elems * 2, hipMemcpyHostToDevice));
-    XV_HIP(h, hipMemcpy(L.wlo.p, lo.data(), elems * 2, hipMemcpyHostToDevice));
+    XV_HIP(h, L.wsb.alloc(elems * 4));
+    XV_HIP(h, hipMemcpy(L.wsb.p, sb.data(), elems * 4, hipMemcpyHostToDevice));
   }
   return XV_OK;
 }
@@ -431,6 +434,13 @@ int64_t value_rows(const xv_handle* h, int vid, int64_t F0, int B) {
 int64_t value_bytes(const xv_handle* h, int vid, int64_t F0, int B) {
   const Value& v = h->values[vid];
   return align_up((value_rows(h, vid, F0, B) + kSlackRows) * (int64_t)v.cols * 4, kAlign);
+}
+
+int sb_ld(int cols) { return (int)align_up(cols, 32); }
+
+int64_t value_sb_bytes(const xv_handle* h, int vid, int64_t F0, int B) {
+  const Value& v = h->values[vid];
+  return align_up((value_rows(h, vid, F0, B) + kSlackRows) * (int64_t)sb_ld(v.cols) * 4, kAlign);
 }
 
 }  // namespace
@@ -506,6 +516,13 @@ int xv_finalize(xv_handle* h) {
     if (!kv.second.set) return fail(h, XV_ERR_MISSING_TENSOR, "variable '%s' was never set", kv.first.c_str());
   DeviceGuard g(h->device);
   if (!g.ok) return fail(h, XV_ERR_HIP, "cannot select HIP device %d", h->device);
+  for (const Op& op : h->ops) {      // which layers run on the bf16x3 kernel
+    if (op.kind != OP_GEMM) continue;
+    Layer& L = h->layers[op.layer];
+    const Value& vin = h->values[op.in0];
+    L.use_split = h->desc.precision == XV_PREC_BF16X3 && op.in0 != 0 && vin.frame_level &&
+                  (L.w == 1 || L.cin % 32 == 0);
+  }
   for (auto& L : h->layers) {
     const int rc = upload_layer(h, L);
     if (rc != XV_OK) return rc;
@@ -628,6 +645,17 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       }
   };
 
+  // which formats of each value are read: fp32 by the f32 GEMM / pooling / elementwise kernels,
+  // split-blocked by the bf16x3 GEMM
+  std::vector<char> want_f32(h->values.size(), 0), want_sb(h->values.size(), 0);
+  for (int o : order) {
+    const Op& op = h->ops[o];
+    const bool split_in = op.kind == OP_GEMM && h->layers[op.layer].use_split;
+    if (op.in0 > 0) (split_in ? want_sb : want_f32)[op.in0] = 1;
+    if (op.in1 > 0) want_f32[op.in1] = 1;
+  }
+  std::vector<int64_t> voff_sb(h->values.size(), -1), vsize_sb(h->values.size(), 0);
+
   int64_t total_flops = 0;
   int64_t rowmap_elems = 0;
   for (size_t s = 0; s < order.size(); ++s) {
@@ -638,6 +666,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     st.rows_in = op.in0 >= 0 ? value_rows(h, op.in0, F0, batch) : 0;
     st.rows_out = value_rows(h, op.out, F0, batch);
     st.in0_off = op.in0 == 0 ? -2 : (op.in0 > 0 ? voff[op.in0] : -1);
+    st.in0_sb_off = op.in0 > 0 ? voff_sb[op.in0] : -1;
     st.in1_off = op.in1 > 0 ? voff[op.in1] : -1;
     if (op.kind == OP_GEMM) {
       const Layer& L = h->layers[op.layer];
@@ -663,21 +692,32 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       st.bytes = 8 * st.rows_out * h->values[op.out].cols;
     }
     total_flops += st.flops;
-    // softmax works in place on the scores buffer; everything else gets its own block
+    // softmax works in place on the scores buffer; everything else gets its own block(s)
     if (op.kind == OP_ATT_SOFTMAX) {
       voff[op.out] = voff[op.in0];
       vsize[op.out] = vsize[op.in0];
       vsize[op.in0] = 0;                 // ownership moves to the softmax value
       st.out_off = voff[op.out];
-    } else if (!st.to_out || node.att_weights) {
-      vsize[op.out] = value_bytes(h, op.out, F0, batch);
-      voff[op.out] = arena_alloc(vsize[op.out]);
-      st.out_off = voff[op.out];
+    } else if (st.to_out && !node.att_weights) {
+      st.out_off = -1;                   // straight into the caller's output buffer (fp32)
+    } else {
+      if (want_f32[op.out] || node.att_weights) {
+        vsize[op.out] = value_bytes(h, op.out, F0, batch);
+        voff[op.out] = arena_alloc(vsize[op.out]);
+        st.out_off = voff[op.out];
+      }
+      if (want_sb[op.out]) {
+        vsize_sb[op.out] = value_sb_bytes(h, op.out, F0, batch);
+        voff_sb[op.out] = arena_alloc(vsize_sb[op.out]);
+        st.out_sb_off = voff_sb[op.out];
+      }
     }
-    if (st.to_out && !node.att_weights) st.out_off = -1;
     p->steps.push_back(st);
     for (int in : {op.in0, op.in1})
-      if (in > 0 && last_use[in] == (int)s && vsize[in] > 0) { arena_free(voff[in], vsize[in]); vsize[in] = 0; }
+      if (in > 0 && last_use[in] == (int)s) {
+        if (vsize[in] > 0) { arena_free(voff[in], vsize[in]); vsize[in] = 0; }
+        if (vsize_sb[in] > 0) { arena_free(voff_sb[in], vsize_sb[in]); vsize_sb[in] = 0; }
+      }
   }
 
   // output shape
@@ -792,6 +832,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
       return o == -2 ? feats : reinterpret_cast<const float*>(ws + o);
     };
     float* optr = st.out_off >= 0 ? reinterpret_cast<float*>(ws + st.out_off) : out;
+    (void)split;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (prof) {
       pe0 = h->prof_pool[h->prof_next++];
@@ -813,10 +854,20 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         a.alpha = (a.act == ACT_PRELU) ? L.d_alpha() : nullptr;
         a.rowmap = st.rowmap >= 0 ? static_cast<const int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.rowmap] : nullptr;
         a.Y = optr; a.ldy = L.cout;
-        const bool aligned = op.in0 != 0 && (a.ldx % 4 == 0) && (a.K % 4 == 0);
-        if (split && op.in0 != 0) {
-          return fail(h, XV_ERR_UNSUPPORTED, "bf16x3 path not built yet");
+        if (st.out_sb_off >= 0) {
+          a.Ysb = ws + st.out_sb_off;
+          a.ldsb = sb_ld(L.cout);
+          if (st.out_off < 0 && !st.to_out) a.Y = nullptr;
         }
+        if (L.use_split) {
+          if (st.in0_sb_off < 0) return fail(h, XV_ERR_STATE, "split layer %s has no split-blocked input", L.kernel_name.c_str());
+          a.Xsb = ws + st.in0_sb_off;
+          a.ldsbx = sb_ld(L.cin);
+          a.Wsb = L.wsb.p;
+          XV_HIP(h, launch_gemm_bf16x3(a, s));
+          break;
+        }
+        const bool aligned = op.in0 != 0 && (a.ldx % 4 == 0) && (a.K % 4 == 0);
         XV_HIP(h, launch_gemm_f32(a, aligned, s));
         break;
       }
@@ -932,7 +983,7 @@ void xv_destroy(xv_handle* h) {
   if (!h) return;
   {
     DeviceGuard g(h->device);
-    for (auto& L : h->layers) { L.wt.release(); L.whi.release(); L.wlo.release(); L.vec.release(); }
+    for (auto& L : h->layers) { L.wt.release(); L.wsb.release(); L.vec.release(); }
     h->query.release();
     h->post_vec.release();
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
