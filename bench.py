@@ -113,30 +113,24 @@ def main():
     info = tr.plan_info(offsets)
     out = torch.empty((int(info["out_rows"]), int(info["out_cols"])), dtype=torch.float32, device=dev)
 
-    def sync_all():
-        if world > 1:
-            dist.barrier()
+    from tf_kaldi_speaker_amd import sharding
+
+    def sync_dev():
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    def step():
         tr.predict_packed(feats, offsets, out=out)
-    sync_all()
+
+    for _ in range(args.warmup):
+        step()
+    sync_dev()
     if not args.no_profile:
         tr.profile_begin(max_events=2 * 16 * (args.steps + 1))
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.predict_packed(feats, offsets, out=out)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    # barrier + synchronize, exactly K steps, barrier + synchronize, max over ranks
+    elapsed = sharding.timed_steps(step, args.steps, sync_dev, dist=dist if world > 1 else None, device=dev)
     kernels = []
     if not args.no_profile:
         kernels, _ = tr.profile_end()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     result = None
     if rank == 0:
         emb = out.cpu().numpy()
