@@ -18,6 +18,8 @@
 // LDS rows are padded to 144 bytes: every ds_read_b128 lane group touches 16 distinct 16-byte
 // slots (conflict free).  Register-staged double buffering, one barrier per K step; 128x128
 // tile per 256-thread workgroup (2x2 waves of 64x64), two workgroups per CU.
+#include <cstdlib>
+
 #include "xv_epilogue.h"
 
 namespace xv {
@@ -102,35 +104,215 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs p, int nMt
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
+          // weights = MFMA A operand, activations = B operand: acc[nj][mi] is D[n][m] (xv_epilogue.h);
           // small cross terms first, the dominant hi*hi term last
-          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[nj], acc[mi][nj], 0, 0, 0);
-          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[nj], acc[mi][nj], 0, 0, 0);
-          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[nj], acc[mi][nj], 0, 0, 0);
+          acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nj], al[mi], acc[nj][mi], 0, 0, 0);
+          acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[nj], ah[mi], acc[nj][mi], 0, 0, 0);
+          acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nj], ah[mi], acc[nj][mi], 0, 0, 0);
         }
     }
     if (kt + 1 < nk) store_tiles(cur ^ 1);
     __syncthreads();
   }
 
+  // the final barrier of the K loop has retired every LDS read: reuse the tiles as store scratch
+  store_wave_tile(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, smem3);
+}
+
+// ------------------------------------------------------------------------------------------
+// 128x128 LDS-DMA kernel (the default): same 2x2 waves of 64x64, two workgroups per CU, but
+//  * operands go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write: the
+//    register-staged kernel above spends ~55% of the LDS port on ds_write_b128 at full MFMA rate);
+//  * LDS rows are unpadded 128-byte blocks (the DMA writes 64 lanes x 16 B linearly), made
+//    conflict-free by an XOR swizzle applied to the per-lane SOURCE address and to the fragment
+//    read address: chunk c of row r lives at r*128 + ((c ^ ((r >> 1) & 7)) << 4);
+//  * convolutions reuse the A slab (frames [m0, m0+128+w-1), one 32-channel block) for all w
+//    taps by shifting the fragment row, so A is staged once per channel block (traffic / w).
+// Schedule per step (one tap of one channel block): issue the DMA of the next step's weight
+// tile and this step's share of the next slab, read 16 fragments, 24 MFMAs, __syncthreads()
+// (whose vmcnt(0) retires the DMA issued ~800 cycles earlier).
+namespace {
+constexpr int DROW = 128;                          // unpadded LDS row
+constexpr int DA_ROWS = 136;                       // 128 + (w-1 <= 7) halo rows, multiple of 8
+constexpr int DA_BYTES = DA_ROWS * DROW;
+constexpr int DB_BYTES = BN * DROW;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+}  // namespace
+
+template <int SCHED>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int nMt, int nNt, int w, int diag) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  char* As = smem3;                      // [2][DA_ROWS][128]
+  char* Bs = smem3 + 2 * DA_BYTES;       // [2][BN][128]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+
+  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
+  const int mt = tile / nNt, nt = tile - mt * nNt;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int ncb = (p.Kpad >> 5) / w;               // channel blocks per frame
+  const int nsteps = (diag & 1) ? 0 : ncb * w;     // diag bit0: skip the main loop (timing only)
+  const int ngroups = (BM + w - 1 + 7) >> 3;        // 8-row DMA groups per slab (16 or 17)
+  const int gps = (ngroups + w - 1) / w;            // groups issued per step
+  // per-lane DMA source: row (lane >> 3) of the group, swizzled chunk
+  const int lrow = lane >> 3, lpc = lane & 7;
+  const int64_t a_row_bytes = p.ldsbx * 4, b_row_bytes = (int64_t)p.Kpad * 4;
+  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + (int64_t)(m0 + lrow) * a_row_bytes;
+  const char* Bg = reinterpret_cast<const char*>(p.Wsb) + (int64_t)(n0 + lrow) * b_row_bytes;
+
+  // group g covers rows 8g .. 8g+7; this lane's row is 8g + lrow and (row >> 1) & 7 == (4g + (lrow >> 1)) & 7
+  auto dma_a = [&](int cb, int buf, int g) {
+    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
+    __builtin_amdgcn_global_load_lds((gptr_t)(Ag + (int64_t)(8 * g) * a_row_bytes + cb * 128 + c * 16),
+                                     (lptr_t)(As + buf * DA_BYTES + g * 1024), 16, 0, 0);
+  };
+  auto dma_b = [&](int kb, int buf, int g) {
+    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
+    __builtin_amdgcn_global_load_lds((gptr_t)(Bg + (int64_t)(8 * g) * b_row_bytes + (int64_t)kb * 128 + c * 16),
+                                     (lptr_t)(Bs + buf * DB_BYTES + g * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-      store_tile_32x32(p, acc[mi][nj], m0 + wm * 64 + mi * 32, n0 + wn * 64 + nj * 32, lane);
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // prologue: whole slab 0 and the weight tile of step 0
+  for (int g = wave; g < ngroups; g += 4) dma_a(0, 0, g);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma_b(0, 0, wave + 4 * q);
+  __syncthreads();
+
+  // B fragment offsets (row fixed per lane): chunk c = plane*4 + ks*2 + h
+  int boff[2];
+  int bswz[2];
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj) {
+    const int rb = wn * 64 + nj * 32 + r32;
+    boff[nj] = rb * DROW;
+    bswz[nj] = (rb >> 1) & 7;
+  }
+
+  int cb = 0, j = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    int cb_next = cb, j_next = j + 1;
+    if (j_next == w) { j_next = 0; cb_next = cb + 1; }
+    if (s + 1 < nsteps) {
+      const int kb = j_next * ncb + cb_next;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma_b(kb, (s + 1) & 1, wave + 4 * q);
+    }
+    if (cb + 1 < ncb) {
+      const int gend = min((j + 1) * gps, ngroups);
+      for (int g = j * gps + wave; g < gend; g += 4) dma_a(cb + 1, (cb + 1) & 1, g);
+    }
+
+    const char* ab = As + (cb & 1) * DA_BYTES;
+    const char* bb = Bs + (s & 1) * DB_BYTES;
+    int aoff[2], aswz[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int ra = wm * 64 + mi * 32 + r32 + j;
+      aoff[mi] = ra * DROW;
+      aswz[mi] = (ra >> 1) & 7;
+    }
+    bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];     // [ks][tile]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ch = ks * 2 + h, cl = 4 + ks * 2 + h;
+        ah[ks][i] = *reinterpret_cast<const bf16x8*>(ab + aoff[i] + ((ch ^ aswz[i]) << 4));
+        al[ks][i] = *reinterpret_cast<const bf16x8*>(ab + aoff[i] + ((cl ^ aswz[i]) << 4));
+        bh[ks][i] = *reinterpret_cast<const bf16x8*>(bb + boff[i] + ((ch ^ bswz[i]) << 4));
+        bl[ks][i] = *reinterpret_cast<const bf16x8*>(bb + boff[i] + ((cl ^ bswz[i]) << 4));
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+          acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks][nj], al[ks][mi], acc[nj][mi], 0, 0, 0);
+          acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ks][nj], ah[ks][mi], acc[nj][mi], 0, 0, 0);
+          acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks][nj], ah[ks][mi], acc[nj][mi], 0, 0, 0);
+        }
+    if (SCHED == 1) {   // all 16 fragment reads first, then the 24 MFMAs back to back
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+    } else if (SCHED == 2) {   // ks=0 reads, ks=1 reads interleaved with the ks=0 MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    }
+    __syncthreads();
+    cb = cb_next;
+    j = j_next;
+  }
+
+  if (diag & 2) {       // diag bit1: skip the epilogue stores (keep the accumulators live)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) asm volatile("" ::"v"(acc[mi][nj]));
+    return;
+  }
+  // the final barrier of the K loop has retired every LDS read: reuse the tiles as store scratch
+  store_wave_tile(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, smem3);
 }
 
 hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
-  const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
-  const size_t smem = (size_t)4 * TILE_B;
+  static int force = -1;        // XVEC_GEMM_TILE=128 pins the register-staged kernel (A/B runs); default = LDS-DMA kernel
   static bool attr_set = false;
+  static int sched = 0, diag = 0;   // XVEC_GEMM_SCHED / XVEC_GEMM_DIAG: tuning & timing-only switches
+  const size_t smem128 = (size_t)4 * TILE_B;
+  const size_t smemdma = (size_t)2 * DA_BYTES + 2 * DB_BYTES;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
+    const char* e = getenv("XVEC_GEMM_TILE");
+    force = e ? atoi(e) : 0;
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
+    if (r != hipSuccess) return r;
+    for (const void* f : {reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<0>),
+                          reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<1>),
+                          reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<2>)}) {
+      r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemdma);
+      if (r != hipSuccess) return r;
+    }
+    const char* e2 = getenv("XVEC_GEMM_SCHED");
+    sched = e2 ? atoi(e2) : 0;
+    const char* e3 = getenv("XVEC_GEMM_DIAG");
+    diag = e3 ? atoi(e3) : 0;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(nMt * nNt), dim3(256), smem, s, a, nMt, nNt);
+  const int w = a.K / a.cin > 0 && a.ldsbx == a.cin ? a.K / a.cin : 1;   // taps (dense: 1)
+  const bool taps_ok = w <= 8 && (a.Kpad >> 5) % w == 0;
+  if (force != 128 && taps_ok) {
+    const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
+    if (sched == 1)
+      hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<1>, dim3(nMt * nNt), dim3(256), smemdma, s, a, nMt, nNt, w, diag);
+    else if (sched == 2)
+      hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<2>, dim3(nMt * nNt), dim3(256), smemdma, s, a, nMt, nNt, w, diag);
+    else
+      hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<0>, dim3(nMt * nNt), dim3(256), smemdma, s, a, nMt, nNt, w, diag);
+    return hipGetLastError();
+  }
+  const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
+  hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(nMt * nNt), dim3(256), smem128, s, a, nMt, nNt);
   return hipGetLastError();
 }
 

@@ -114,21 +114,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, i
       f32x4 b1 = *reinterpret_cast<const f32x4*>(bp + 32 * LDT + q * 8);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+        // weights = MFMA A operand, activations = B operand: acc[ni][mi] is D[n][m] (xv_epilogue.h)
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[j], a0[j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[j], a1[j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[j], a0[j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[j], a1[j], acc[1][1], 0, 0, 0);
       }
     }
     if (kt + 1 < nk) store_tiles(cur ^ 1);
     __syncthreads();
   }
 
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-      store_tile_32x32(p, acc[mi][nj], m0 + wm * 64 + mi * 32, n0 + wn * 64 + nj * 32, lane);
+  // the final barrier of the K loop has retired every LDS read: reuse the tiles as store scratch
+  store_wave_tile(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, reinterpret_cast<char*>(smem));
 }
 
 hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s) {

@@ -25,18 +25,16 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   }
 }
 
-// round-to-nearest-even fp32 -> bf16 bits (finite inputs; NaN propagates as a quiet NaN)
-__device__ __forceinline__ uint32_t bf16_rn_bits(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-// (hi | lo << 16) split of one fp32 value
-__device__ __forceinline__ uint32_t split_pack(float v) {
-  const uint32_t hi = bf16_rn_bits(v);
-  const float r = v - __uint_as_float(hi << 16);
-  return hi | (bf16_rn_bits(r) << 16);
+// hi/lo bf16 split of two fp32 values, packed {a | b << 16}: v_cvt_pk_bf16_f32 (RNE, NaN-safe),
+// shl/and, v_pk_add_f32, v_cvt_pk_bf16_f32 = 2.5 VALU instructions per value.
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const f32x2_t v = {a, b};
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+  const f32x2_t hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - hf, bf16x2_t));
 }
 
 // XCD-aware bijective remap of a 1-D grid (ids congruent mod 8 share an XCD and its L2).
@@ -45,37 +43,149 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-// Store one 32x32 accumulator tile.  C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) +
-// 4 * (lane >> 5).  `mbase`/`nbase` are the tile's first row / column (nbase % 32 == 0).
-// Writes fp32 Y and/or the SB planes; for SB also zero-fills the padding columns [N, ldsb).
-__device__ __forceinline__ void store_tile_32x32(const GemmArgs& p, const f32x16& acc, int mbase, int nbase,
-                                                 int lane) {
+// ---------------------------------------------------------------------------------------------
+// Accumulator orientation used by every GEMM kernel here: the WEIGHT fragment is the MFMA A
+// operand and the ACTIVATION fragment the B operand, so a 32x32 result tile is D[n][m]:
+//   lane & 31            -> frame m (row of the output matrix)
+//   (e&3) + 8*(e>>2) + 4*(lane>>5) -> channel n, i.e. registers 4q..4q+3 are FOUR CONSECUTIVE
+//                                     channels 8q + 4*(lane>>5) .. +3 of one frame.
+// A lane can therefore apply per-channel scale/shift with float4 loads, split to bf16 in packed
+// pairs and emit 8/16-byte LDS writes with no cross-lane traffic.
+
+// Scalar fallback (any N / alignment): one element at a time, fp32 and/or split-blocked.
+__device__ __forceinline__ void store_tile_scalar(const GemmArgs& p, const f32x16& acc, int mbase, int nbase, int lane) {
   const int r32 = lane & 31, h = lane >> 5;
-  const int n = nbase + r32;
-  const bool nok = n < p.N;
-  const float sc = nok ? p.scale[n] : 0.f;
-  const float sh = nok ? p.shift[n] : 0.f;
-  const float al = (nok && p.alpha) ? p.alpha[n] : 0.f;
-  const bool sb_col = p.Ysb && n < p.ldsb;       // column exists in the SB row (value or zero padding)
+  const int m = mbase + r32;
+  int orow = -1;
+  if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+  if (orow < 0) return;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-    int orow = -1;
-    if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
-    const float v = nok ? apply_act(fmaf(acc[e], sc, sh), p.act, al) : 0.f;
-    if (p.Y && nok && orow >= 0) p.Y[(int64_t)orow * p.ldy + n] = v;
-    if (p.Ysb) {
-      // pair adjacent columns so every lane stores one dword: even lane -> hi plane, odd -> lo plane
-      const uint32_t mine = split_pack(v);
-      const uint32_t other = __shfl_xor(mine, 1, 64);
-      const uint32_t word = (lane & 1) ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
-      if (sb_col && orow >= 0) {
-        char* row = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4;
-        const int blk = n >> 5, c = (n & 31) & ~1;
-        *reinterpret_cast<uint32_t*>(row + blk * 128 + (lane & 1) * 64 + c * 2) = word;
-      }
+    const int n = nbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+    const bool nok = n < p.N;
+    const float v = nok ? apply_act(fmaf(acc[e], p.scale[n], p.shift[n]), p.act, p.alpha ? p.alpha[n] : 0.f) : 0.f;
+    if (p.Y && nok) p.Y[(int64_t)orow * p.ldy + n] = v;
+    if (p.Ysb && n < p.ldsb) {
+      uint32_t hi, lo;
+      split2(v, 0.f, hi, lo);
+      uint16_t* blk = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128);
+      blk[n & 31] = (uint16_t)hi;
+      blk[32 + (n & 31)] = (uint16_t)lo;
     }
   }
+}
+
+// LDS-staged epilogue of a 64x64 wave tile acc[ni][mi] (2x2 MFMA tiles, orientation above).
+// The wave writes its post-activation tile into a private 16 KB LDS scratch shaped like the
+// destination rows (256 bytes per frame: two SB blocks, or 64 floats; 16-byte chunks XOR-swizzled
+// by frame & 15), then reads it back 16 bytes per lane and stores whole 256-byte row segments.
+// Requirements (wide_epilogue_ok): N % 4 == 0, ldy % 4 == 0, 16-byte aligned Y.  All waves of the
+// workgroup call it (contains __syncthreads()); `lds` is the workgroup's LDS base, >= 16 KB per
+// wave, no longer read by the main loop.
+template <int ACT>
+__device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f32x16 (&acc)[2][2], int mbase, int nbase,
+                                                     int lane, int wave, char* lds) {
+  const int r32 = lane & 31, h = lane >> 5;
+  char* scratch = lds + wave * 16384;
+  const int rrow = lane >> 4, rchunk = lane & 15;       // read-back map: 4 frames x 16 chunks per pass
+
+  auto value4 = [&](const f32x16& t, int q, const f32x4& sc, const f32x4& sh, const f32x4& al) -> f32x4 {
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = apply_act(fmaf(t[4 * q + i], sc[i], sh[i]), ACT < 0 ? p.act : ACT, al[i]);
+    return v;
+  };
+  auto params = [&](int n4, f32x4& sc, f32x4& sh, f32x4& al) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const bool ok = n4 < p.N;
+    sc = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
+    sh = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
+    al = (ok && p.alpha) ? *reinterpret_cast<const f32x4*>(p.alpha + n4) : z;
+  };
+
+  if (p.Ysb) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 sc, sh, al;
+        params(nbase + ni * 32 + 8 * q + 4 * h, sc, sh, al);     // padding channels: scale = shift = 0 -> 0
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const f32x4 v = value4(acc[ni][mi], q, sc, sh, al);
+          uint32_t h01, l01, h23, l23;
+          split2(v[0], v[1], h01, l01);
+          split2(v[2], v[3], h23, l23);
+          const int row = mi * 32 + r32;
+          char* rp = scratch + row * 256 + 8 * h;
+          *reinterpret_cast<uint2*>(rp + (((ni * 8 + q) ^ (row & 15)) << 4)) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(rp + (((ni * 8 + 4 + q) ^ (row & 15)) << 4)) = make_uint2(l01, l23);
+        }
+      }
+    __syncthreads();
+    const bool blk_ok = nbase + (rchunk >> 3) * 32 < p.ldsb;     // SB block exists in the output row
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + rrow;
+      const int m = mbase + row;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
+      int orow = -1;
+      if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+      if (orow >= 0 && blk_ok)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (nbase >> 5) * 128 +
+                                  rchunk * 16) = v;
+    }
+    if (p.Y) __syncthreads();
+  }
+  if (p.Y) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 sc, sh, al;
+        params(nbase + ni * 32 + 8 * q + 4 * h, sc, sh, al);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row = mi * 32 + r32;
+          *reinterpret_cast<f32x4*>(scratch + row * 256 + (((ni * 8 + 2 * q + h) ^ (row & 15)) << 4)) =
+              value4(acc[ni][mi], q, sc, sh, al);
+        }
+      }
+    __syncthreads();
+    const int n = nbase + rchunk * 4;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + rrow;
+      const int m = mbase + row;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
+      int orow = -1;
+      if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+      if (orow >= 0 && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
+    }
+  }
+}
+
+// true when the vectorised LDS-staged epilogue applies to this launch
+__device__ __forceinline__ bool wide_epilogue_ok(const GemmArgs& p) {
+  return (p.N & 3) == 0 && (!p.Y || ((p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0));
+}
+
+// Epilogue entry for a 64x64 wave tile: LDS-staged wide stores when the shape allows, scalar otherwise.
+__device__ __forceinline__ void store_wave_tile(const GemmArgs& p, const f32x16 (&acc)[2][2], int mbase, int nbase,
+                                                int lane, int wave, char* lds) {
+  if (wide_epilogue_ok(p)) {
+    if (p.act == ACT_RELU)
+      store_wave_tile_impl<ACT_RELU>(p, acc, mbase, nbase, lane, wave, lds);
+    else if (p.act == ACT_NONE)
+      store_wave_tile_impl<ACT_NONE>(p, acc, mbase, nbase, lane, wave, lds);
+    else
+      store_wave_tile_impl<-1>(p, acc, mbase, nbase, lane, wave, lds);
+    return;
+  }
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) store_tile_scalar(p, acc[ni][mi], mbase + mi * 32, nbase + ni * 32, lane);
 }
 
 }  // namespace xv

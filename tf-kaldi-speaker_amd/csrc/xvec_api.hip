@@ -21,7 +21,7 @@ using namespace xv;
 namespace {
 
 constexpr double kBnEps = 1e-3;        // tf.layers.batch_normalization default epsilon
-constexpr int kSlackRows = 160;        // readable rows after every activation buffer (GEMM tile overreach)
+constexpr int kSlackRows = 320;        // readable rows after every activation buffer (GEMM tile overreach)
 constexpr int kAlign = 256;
 
 thread_local std::string g_last_error;  // failures with no handle (xv_create)
