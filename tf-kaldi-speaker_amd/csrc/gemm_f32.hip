@@ -30,7 +30,7 @@ constexpr int LDT = BK + 4;               // padded LDS row (floats)
 constexpr int TILE_F = BM * LDT;          // floats per operand tile
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, int nNt) {
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, int nNt, int kper) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][BM][LDT]
   float* Bs = smem + 2 * TILE_F;    // [2][BN][LDT]
@@ -40,13 +40,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, i
   const int wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
 
-  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
+  const int ntiles = nMt * nNt;
+  const int slice = blockIdx.x / ntiles;                       // split-K slice (0 when off)
+  const int tile = xcd_remap(blockIdx.x - slice * ntiles, ntiles);
   const int mt = tile / nNt, nt = tile - mt * nNt;
   const int m0 = mt * BM, n0 = nt * BN;
 
   // staging map: thread -> (row lr + 32*i, float4 column c4)
   const int c4 = tid & 7, lr = tid >> 3;
-  const int nk = p.Kpad / BK;
+  const int kt0 = slice * kper;
+  const int nk = min(p.Kpad / BK, kt0 + kper);
+  if (p.ksplit > 1) {                                           // raw partial sums of this slice
+    p.Y = p.partial + (int64_t)slice * p.M * p.Npad;
+    p.ldy = p.Npad;
+    p.N = p.Npad;
+    p.Ysb = nullptr;
+    p.rowmap = nullptr;
+    p.raw = 1;
+    p.act = ACT_NONE;
+  }
 
   f32x4 ra[4], rb[4];
   auto load_tiles = [&](int kt) {
@@ -94,15 +106,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, i
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  load_tiles(0);
+  load_tiles(kt0);
   store_tiles(0);
   __syncthreads();
 
   const float* a_base = As + (wm * 64 + r32) * LDT + 4 * h;
   const float* b_base = Bs + (wn * 64 + r32) * LDT + 4 * h;
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int cur = (kt - kt0) & 1;
     if (kt + 1 < nk) load_tiles(kt + 1);
     const float* ap = a_base + cur * TILE_F;
     const float* bp = b_base + cur * TILE_F;
@@ -129,9 +141,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, i
   store_wave_tile(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, reinterpret_cast<char*>(smem));
 }
 
+// out[m][n] = act((sum_s partial[s][m][n]) * scale[n] + shift[n]); slices summed in index order.
+__global__ void splitk_reduce_kernel(GemmArgs p) {
+  const int64_t total = (int64_t)p.M * p.N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / p.N), n = (int)(i - (int64_t)m * p.N);
+    float acc = 0.f;
+    for (int s = 0; s < p.ksplit; ++s) acc += p.partial[((int64_t)s * p.M + m) * p.Npad + n];
+    const float v = apply_act(fmaf(acc, p.scale[n], p.shift[n]), p.act, p.alpha ? p.alpha[n] : 0.f);
+    const int orow = p.rowmap ? p.rowmap[m] : m;
+    if (orow >= 0) p.Y[(int64_t)orow * p.ldy + n] = v;
+  }
+}
+
+int gemm_f32_ksplit(int M, int Kpad, int Npad) {
+  if (M > 512) return 1;                       // frame-level layers fill the chip on their own
+  const int tiles = ((M + BM - 1) / BM) * (Npad / BN), nk = Kpad / BK;
+  int s = 512 / (tiles > 0 ? tiles : 1);
+  if (s > nk / 4) s = nk / 4;                  // at least four K tiles per slice
+  return s < 2 ? 1 : s;
+}
+
 hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
+  const int ks = (a.ksplit > 1 && a.partial && !a.Ysb) ? a.ksplit : 1;
+  const int nk_all = a.Kpad / BK;
+  const int kper = (nk_all + ks - 1) / ks;
   const size_t smem = (size_t)4 * TILE_F * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -143,11 +179,18 @@ hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  dim3 grid(nMt * nNt), block(256);
+  GemmArgs b = a;
+  b.ksplit = ks;
+  dim3 grid(nMt * nNt * ks), block(256);
   if (aligned)
-    hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, block, smem, s, a, nMt, nNt);
+    hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, block, smem, s, b, nMt, nNt, kper);
   else
-    hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, block, smem, s, a, nMt, nNt);
+    hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, block, smem, s, b, nMt, nNt, kper);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || ks == 1) return e;
+  const int64_t total = (int64_t)a.M * a.N;
+  const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, b);
   return hipGetLastError();
 }
 

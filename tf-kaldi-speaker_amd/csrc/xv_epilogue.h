@@ -97,6 +97,12 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
   };
   auto params = [&](int n4, f32x4& sc, f32x4& sh, f32x4& al) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (p.raw) {                                    // split-K partial: accumulators unchanged
+      sc = f32x4{1.f, 1.f, 1.f, 1.f};
+      sh = z;
+      al = z;
+      return;
+    }
     const bool ok = n4 < p.N;
     sc = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
     sh = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;

@@ -40,11 +40,26 @@ struct GemmArgs {
   void* Ysb;              // SB output or nullptr
   int ldsb;               // channels per SB output row incl. zero padding (multiple of 32)
   const void* Wsb;        // packed weights in SB format [Npad][Kpad/32][128 bytes]
+  // split-K (fp32 kernel, small-M segment layers): slice s of `ksplit` accumulates K tiles
+  // [s*kper, (s+1)*kper) and writes RAW accumulators to partial[s][M][Npad]; a reduce kernel
+  // sums the slices in order (deterministic) and applies the epilogue.
+  int ksplit;             // 0/1 = off
+  int raw;                // epilogue: store acc unchanged (scale 1, shift 0, no activation)
+  float* partial;         // [ksplit][M][Npad] fp32 workspace
 };
 
 // fp32 MFMA (v_mfma_f32_32x32x2_f32) path.  aligned: ldx == cin (or K == cin), ldx % 4 == 0,
 // K % 4 == 0, X 16-byte aligned and followed by >= 160 rows of readable slack.
 hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s);
+
+// number of K slices launch_gemm_f32 will use for this shape (1 = no split); the caller provides
+// `partial` of ksplit * M * Npad floats when > 1.
+int gemm_f32_ksplit(int M, int Kpad, int Npad);
+
+// fp32 frames -> split-blocked im2col rows for a small-cin first layer:
+//   out row m, k < w*cin: x[(m + k / cin) * ldx + k % cin]; zero padded to ldsb columns.
+hipError_t launch_im2col_sb(const float* x, int64_t ldx, int cin, int w, int64_t rows, void* out_sb, int ldsb,
+                            hipStream_t s);
 
 // bf16x3 split path (3x v_mfma_f32_32x32x16_bf16 per product tile).
 hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s);

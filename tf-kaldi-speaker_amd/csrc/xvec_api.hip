@@ -75,6 +75,7 @@ struct Layer {
   DevBuf wt;                  // fp32 [Npad][Kpad]                      (fp32 MFMA kernel)
   DevBuf wsb;                 // split-blocked bf16 hi/lo [Npad][Kpad/32][128 B] (bf16x3 kernel)
   bool use_split = false;     // this layer runs on the bf16x3 kernel
+  bool im2col = false;        // first layer in bf16x3 mode: fp32 frames -> SB im2col rows -> dense split GEMM
   DevBuf vec;                 // [bias | bn_scale | bn_shift | alpha | ones] each cout floats
   int Kpad = 0, Npad = 0;
   int final_stage() const { return act != ACT_NONE ? ST_ACT : (has_bn ? ST_BN : ST_AFFINE); }
@@ -156,6 +157,8 @@ struct PlanStep {
   int64_t rows_in = 0, rows_out = 0;
   int M = 0;                    // GEMM rows to compute
   int rowmap = -1;              // index into plan rowmaps (conv layers)
+  int64_t scratch_off = -1;     // per-step scratch (im2col rows / split-K partials), released after the step
+  int ksplit = 1;               // split-K slices of a small-M fp32 GEMM
   int64_t flops = 0, bytes = 0;
 };
 
@@ -520,8 +523,9 @@ int xv_finalize(xv_handle* h) {
     if (op.kind != OP_GEMM) continue;
     Layer& L = h->layers[op.layer];
     const Value& vin = h->values[op.in0];
-    L.use_split = h->desc.precision == XV_PREC_BF16X3 && op.in0 != 0 && vin.frame_level &&
-                  (L.w == 1 || L.cin % 32 == 0);
+    L.im2col = h->desc.precision == XV_PREC_BF16X3 && op.in0 == 0;
+    L.use_split = L.im2col || (h->desc.precision == XV_PREC_BF16X3 && vin.frame_level &&
+                               (L.w == 1 || L.cin % 32 == 0));
   }
   for (auto& L : h->layers) {
     const int rc = upload_layer(h, L);
@@ -661,6 +665,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
   for (size_t s = 0; s < order.size(); ++s) {
     const Op& op = h->ops[order[s]];
     PlanStep st;
+    int64_t step_scratch = 0;            // released once this step's outputs are placed
     st.op = order[s];
     st.to_out = (order[s] == node.op);
     st.rows_in = op.in0 >= 0 ? value_rows(h, op.in0, F0, batch) : 0;
@@ -679,6 +684,17 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       }
       st.flops = 2 * st.rows_out * (int64_t)L.cout * L.w * L.cin;
       st.bytes = 4 * (st.rows_in * L.cin + st.rows_out * L.cout + (int64_t)L.w * L.cin * L.cout);
+      int64_t scratch = 0;
+      if (L.im2col) {
+        scratch = (st.M + kSlackRows) * (int64_t)L.Kpad * 4;
+      } else if (!L.use_split) {
+        st.ksplit = gemm_f32_ksplit(st.M, L.Kpad, L.Npad);
+        if (st.ksplit > 1) scratch = (int64_t)st.ksplit * st.M * L.Npad * 4;
+      }
+      if (scratch > 0) {
+        step_scratch = align_up(scratch, kAlign);
+        st.scratch_off = arena_alloc(step_scratch);
+      }
     } else if (op.kind == OP_AFFINE_ACT) {
       st.stage = st.to_out ? node.stage : 2;
       st.bytes = 8 * st.rows_out * h->values[op.out].cols;
@@ -713,6 +729,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       }
     }
     p->steps.push_back(st);
+    if (step_scratch > 0) arena_free(st.scratch_off, step_scratch);
     for (int in : {op.in0, op.in1})
       if (in > 0 && last_use[in] == (int)s) {
         if (vsize[in] > 0) { arena_free(voff[in], vsize[in]); vsize[in] = 0; }
@@ -859,6 +876,18 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           a.ldsb = sb_ld(L.cout);
           if (st.out_off < 0 && !st.to_out) a.Y = nullptr;
         }
+        if (L.im2col) {
+          // 30-dim first layer on the split kernel: materialise the w*cin-wide rows once (SB
+          // format, K padded to 32), then it is a dense layer on those rows
+          if (st.scratch_off < 0) return fail(h, XV_ERR_STATE, "im2col layer has no scratch");
+          XV_HIP(h, launch_im2col_sb(feats, feat_ld, L.cin, L.w, st.M, ws + st.scratch_off, L.Kpad, s));
+          a.Xsb = ws + st.scratch_off;
+          a.ldsbx = L.Kpad;
+          a.cin = a.K;
+          a.Wsb = L.wsb.p;
+          XV_HIP(h, launch_gemm_bf16x3(a, s));
+          break;
+        }
         if (L.use_split) {
           if (st.in0_sb_off < 0) return fail(h, XV_ERR_STATE, "split layer %s has no split-blocked input", L.kernel_name.c_str());
           a.Xsb = ws + st.in0_sb_off;
@@ -866,6 +895,10 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           a.Wsb = L.wsb.p;
           XV_HIP(h, launch_gemm_bf16x3(a, s));
           break;
+        }
+        if (st.ksplit > 1 && st.scratch_off >= 0) {
+          a.ksplit = st.ksplit;
+          a.partial = reinterpret_cast<float*>(ws + st.scratch_off);
         }
         const bool aligned = op.in0 != 0 && (a.ldx % 4 == 0) && (a.K % 4 == 0);
         XV_HIP(h, launch_gemm_f32(a, aligned, s));
