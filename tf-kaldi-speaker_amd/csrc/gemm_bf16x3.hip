@@ -206,12 +206,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
   for (int s = 0; s < nsteps; ++s) {
     int cb_next = cb, j_next = j + 1;
     if (j_next == w) { j_next = 0; cb_next = cb + 1; }
-    if (s + 1 < nsteps) {
+    if (s + 1 < nsteps && !(diag & 4)) {   // diag bit2: no weight DMA in the loop (timing only)
       const int kb = j_next * ncb + cb_next;
 #pragma unroll
       for (int q = 0; q < 4; ++q) dma_b(kb, (s + 1) & 1, wave + 4 * q);
     }
-    if (cb + 1 < ncb) {
+    if (cb + 1 < ncb && !(diag & 8)) {     // diag bit3: no slab DMA in the loop (timing only)
       const int gend = min((j + 1) * gps, ngroups);
       for (int g = j * gps + wave; g < gend; g += 4) dma_a(cb + 1, (cb + 1) & 1, g);
     }
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     }
-    __syncthreads();
+    if (!(diag & 16)) __syncthreads();     // diag bit4: no barrier (timing only, racy)
     cb = cb_next;
     j = j_next;
   }
@@ -274,13 +274,173 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
   store_wave_tile(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, smem3);
 }
 
+// ------------------------------------------------------------------------------------------
+// 256x128 software-pipelined kernel (large M): 512 threads = 8 waves (4 along M x 2 along N) of
+// 64x64, one workgroup per CU.  Same DMA staging / swizzle / slab reuse as the kernel above, plus
+//  * half the weight traffic per FLOP (each 128x32 weight tile feeds 256 frames);
+//  * a 3-deep LDS ring for the weight tiles (and for the slab when w == 1): the DMA for step s+2
+//    is issued in step s, so a tile has a whole step to land before anyone reads it;
+//  * register double-buffered fragments: the 16 ds_read_b128 of step s+1 are issued BEFORE the
+//    24 MFMAs of step s, so the MFMA stream of a wave never waits on LDS.
+// Ablation on the 128x128 kernel (profiles/): ds_read + MFMA alone run at ~87 % of the clock-
+// adjusted MFMA peak; DMA traffic costs 24 % and the barrier 4 % of the loop.
+namespace {
+constexpr int PBM = 256, PNT = 512;
+constexpr int PA_ROWS = PBM + 8;                   // slab rows incl. w-1 <= 7 halo rows
+constexpr int PA_BYTES = PA_ROWS * DROW;           // 33792
+constexpr int PB_BYTES = BN * DROW;                // 16384
+struct Frags { bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2]; };   // [k16 step][tile]
+}  // namespace
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_pipe_kernel(GemmArgs p, int nMt, int nNt, int w) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  char* As = smem3;                      // [3][PA_ROWS][128]
+  char* Bs = smem3 + 3 * PA_BYTES;       // [3][BN][128]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+
+  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
+  const int mt = tile / nNt, nt = tile - mt * nNt;
+  const int m0 = mt * PBM, n0 = nt * BN;
+
+  const int ncb = (p.Kpad >> 5) / w;               // channel blocks per frame
+  const int nsteps = ncb * w;
+  const int ngroups = (PBM + w - 1 + 7) >> 3;       // 8-row DMA groups per slab (32 or 33)
+  const int aring = (w == 1) ? 3 : 2;               // slab ring depth
+  const int gps = (w == 1) ? ngroups : (ngroups + w - 2) / (w - 1);   // slab groups issued per step
+  const int lrow = lane >> 3, lpc = lane & 7;
+  const int64_t a_row_bytes = p.ldsbx * 4, b_row_bytes = (int64_t)p.Kpad * 4;
+  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + (int64_t)(m0 + lrow) * a_row_bytes;
+  const char* Bg = reinterpret_cast<const char*>(p.Wsb) + (int64_t)(n0 + lrow) * b_row_bytes;
+
+  auto dma_a = [&](int cb, int buf, int g) {
+    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
+    __builtin_amdgcn_global_load_lds((gptr_t)(Ag + (int64_t)(8 * g) * a_row_bytes + cb * 128 + c * 16),
+                                     (lptr_t)(As + buf * PA_BYTES + g * 1024), 16, 0, 0);
+  };
+  auto dma_b = [&](int kb, int buf, int g) {
+    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
+    __builtin_amdgcn_global_load_lds((gptr_t)(Bg + (int64_t)(8 * g) * b_row_bytes + (int64_t)kb * 128 + c * 16),
+                                     (lptr_t)(Bs + buf * PB_BYTES + g * 1024), 16, 0, 0);
+  };
+
+  // B fragment offsets (row fixed per lane): chunk c = plane*4 + ks*2 + h
+  int boff[2], bswz[2];
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj) {
+    const int rb = wn * 64 + nj * 32 + r32;
+    boff[nj] = rb * DROW;
+    bswz[nj] = (rb >> 1) & 7;
+  }
+  auto read_frags = [&](Frags& f, int abuf, int j, int bbuf) {
+    const char* ab = As + abuf * PA_BYTES;
+    const char* bb = Bs + bbuf * PB_BYTES;
+    int aoff[2], aswz[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int ra = wm * 64 + mi * 32 + r32 + j;
+      aoff[mi] = ra * DROW;
+      aswz[mi] = (ra >> 1) & 7;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ch = ks * 2 + h, cl = 4 + ks * 2 + h;
+        f.ah[ks][i] = *reinterpret_cast<const bf16x8*>(ab + aoff[i] + ((ch ^ aswz[i]) << 4));
+        f.al[ks][i] = *reinterpret_cast<const bf16x8*>(ab + aoff[i] + ((cl ^ aswz[i]) << 4));
+        f.bh[ks][i] = *reinterpret_cast<const bf16x8*>(bb + boff[i] + ((ch ^ bswz[i]) << 4));
+        f.bl[ks][i] = *reinterpret_cast<const bf16x8*>(bb + boff[i] + ((cl ^ bswz[i]) << 4));
+      }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto mfma24 = [&](const Frags& f) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+          acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[ks][nj], f.al[ks][mi], acc[nj][mi], 0, 0, 0);
+          acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bl[ks][nj], f.ah[ks][mi], acc[nj][mi], 0, 0, 0);
+          acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[ks][nj], f.ah[ks][mi], acc[nj][mi], 0, 0, 0);
+        }
+  };
+
+  // (cb, j) of steps s, s+1, s+2 and their ring slots, advanced incrementally
+  int cb0 = 0, j0 = 0, cb1 = 0, j1 = 1, cb2 = 0, j2 = 2;
+  auto norm = [&](int& cb, int& j) { while (j >= w) { j -= w; ++cb; } };
+  norm(cb1, j1);
+  norm(cb2, j2);
+  int b0 = 0, b1 = 1, b2 = 2;            // weight ring slots of steps s, s+1, s+2
+
+  // prologue: slab 0 (and slab 1 when w == 1), weight tiles of steps 0 and 1
+  for (int g = wave; g < ngroups; g += 8) dma_a(0, 0, g);
+  if (w == 1 && ncb > 1)
+    for (int g = wave; g < ngroups; g += 8) dma_a(1, 1, g);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) dma_b(0, 0, wave + 8 * q);
+  if (nsteps > 1) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) dma_b(j1 * ncb + cb1, 1, wave + 8 * q);
+  }
+  __syncthreads();
+
+  Frags f0, f1;
+  read_frags(f0, 0, 0, 0);
+
+  auto body = [&](int s, const Frags& fc, Frags& fn) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): fragments of step s are in registers
+    // DMA two steps ahead: weight tile of step s+2, and this step's share of the next slab
+    if (s + 2 < nsteps) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) dma_b(j2 * ncb + cb2, b2, wave + 8 * q);
+    }
+    if (w == 1) {
+      if (cb0 + 2 < ncb)
+        for (int g = wave; g < ngroups; g += 8) dma_a(cb0 + 2, (cb0 + 2) % 3, g);
+    } else if (cb0 + 1 < ncb && j0 < w - 1) {
+      const int gend = min((j0 + 1) * gps, ngroups);
+      for (int g = j0 * gps + wave; g < gend; g += 8) dma_a(cb0 + 1, (cb0 + 1) & 1, g);
+    }
+    // fragments of step s+1 (their tiles landed before the previous barrier)
+    if (s + 1 < nsteps) read_frags(fn, aring == 3 ? cb1 % 3 : (cb1 & 1), j1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma24(fc);
+    __syncthreads();
+    cb0 = cb1; j0 = j1; cb1 = cb2; j1 = j2;
+    ++j2; if (j2 == w) { j2 = 0; ++cb2; }
+    const int t = b0; b0 = b1; b1 = b2; b2 = t;
+  };
+
+  for (int s = 0; s < nsteps; s += 2) {
+    body(s, f0, f1);
+    if (s + 1 < nsteps) body(s + 1, f1, f0);
+  }
+
+  // the final barrier of the K loop has retired every LDS read: reuse the ring as store scratch
+  store_wave_tile(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, smem3);
+}
+
 hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
-  static int force = -1;        // XVEC_GEMM_TILE=128 pins the register-staged kernel (A/B runs); default = LDS-DMA kernel
+  static int force = -1;        // XVEC_GEMM_TILE=128 register-staged | 1 DMA 128x128 | 256 pipelined 256x128; 0 = by size
   static bool attr_set = false;
   static int sched = 0, diag = 0;   // XVEC_GEMM_SCHED / XVEC_GEMM_DIAG: tuning & timing-only switches
   const size_t smem128 = (size_t)4 * TILE_B;
   const size_t smemdma = (size_t)2 * DA_BYTES + 2 * DB_BYTES;
+  const size_t smempipe = (size_t)3 * PA_BYTES + 3 * PB_BYTES;
   if (!attr_set) {
     const char* e = getenv("XVEC_GEMM_TILE");
     force = e ? atoi(e) : 0;
@@ -293,6 +453,9 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
       r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemdma);
       if (r != hipSuccess) return r;
     }
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_pipe_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smempipe);
+    if (r != hipSuccess) return r;
     const char* e2 = getenv("XVEC_GEMM_SCHED");
     sched = e2 ? atoi(e2) : 0;
     const char* e3 = getenv("XVEC_GEMM_DIAG");
@@ -301,6 +464,11 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
   }
   const int w = a.K / a.cin > 0 && a.ldsbx == a.cin ? a.K / a.cin : 1;   // taps (dense: 1)
   const bool taps_ok = w <= 8 && (a.Kpad >> 5) % w == 0;
+  if (taps_ok && (force == 256 || (force == 0 && a.M >= 4096))) {
+    const int nMt = (a.M + PBM - 1) / PBM, nNt = a.Npad / BN;
+    hipLaunchKernelGGL(gemm_bf16x3_pipe_kernel, dim3(nMt * nNt), dim3(PNT), smempipe, s, a, nMt, nNt, w);
+    return hipGetLastError();
+  }
   if (force != 128 && taps_ok) {
     const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
     if (sched == 1)
