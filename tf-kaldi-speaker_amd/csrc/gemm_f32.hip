@@ -165,7 +165,7 @@ int gemm_f32_ksplit(int M, int Kpad, int Npad) {
 hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
-  const int ks = (a.ksplit > 1 && a.partial && !a.Ysb) ? a.ksplit : 1;
+  const int ks = (a.ksplit > 1 && a.partial && !a.Ysb && !a.pool_part) ? a.ksplit : 1;
   const int nk_all = a.Kpad / BK;
   const int kper = (nk_all + ks - 1) / ks;
   const size_t smem = (size_t)4 * TILE_F * sizeof(float);

@@ -53,6 +53,62 @@ hipError_t launch_build_rowmap(const int32_t* off0, int B, int ctx_in, int w, in
   return hipGetLastError();
 }
 
+__global__ void build_row2utt_kernel(const int32_t* __restrict__ off0, int B, int ctx, int32_t* __restrict__ row2utt,
+                                     int M) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= M) return;
+  int lo = 0, hi = B - 1;            // largest b with first row <= r
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (off0[mid] - mid * ctx <= r) lo = mid; else hi = mid - 1;
+  }
+  row2utt[r] = (r < off0[lo + 1] - (lo + 1) * ctx) ? lo : -1;
+}
+
+hipError_t launch_build_row2utt(const int32_t* off0, int B, int ctx, int32_t* row2utt, int M, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(build_row2utt_kernel, dim3((M + 255) / 256), dim3(256), 0, s, off0, B, ctx, row2utt, M);
+  return hipGetLastError();
+}
+
+// Fused statistics pooling, second half: merge the per-segment statistics of one utterance in
+// slot order (deterministic).  Segment i has n_i frames, sum s_i and M2_i = sum (x - s_i/n_i)^2:
+//   mean = sum s_i / L,   M2 = sum [ M2_i + n_i (s_i/n_i - mean)^2 ]   (Chan et al. pairwise merge)
+// which equals the reference's two-pass mean / squared-difference variance (model/pooling.py:41-48)
+// up to fp32 rounding.  grid (ceil(C/256), B).
+__global__ __launch_bounds__(256) void pool_finalize_kernel(const float* __restrict__ part, int C,
+                                                            const int32_t* __restrict__ off0, int ctx,
+                                                            const int32_t* __restrict__ slotbase,
+                                                            float* __restrict__ out, int64_t ldo) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= C) return;
+  const int r0 = off0[b] - b * ctx, r1 = off0[b + 1] - (b + 1) * ctx;
+  const int t0 = r0 >> 6, t1 = (r1 - 1) >> 6;
+  const int64_t base = (int64_t)slotbase[b];
+  float s = 0.f;
+  for (int t = t0; t <= t1; ++t) s += part[((base + t) * 2) * C + n];
+  const float mean = s / (float)(r1 - r0);
+  float m2 = 0.f;
+  for (int t = t0; t <= t1; ++t) {
+    const int ni = min(r1, (t + 1) << 6) - max(r0, t << 6);
+    const float d = part[((base + t) * 2) * C + n] / (float)ni - mean;
+    m2 += part[((base + t) * 2 + 1) * C + n] + (float)ni * d * d;
+  }
+  float var = m2 / (float)(r1 - r0);
+  var = var <= kVarFloor ? kVarFloor : var;                     // model/pooling.py:46-48
+  out[(int64_t)b * ldo + n] = mean;
+  out[(int64_t)b * ldo + C + n] = sqrtf(var);
+}
+
+hipError_t launch_pool_finalize(const float* part, int C, const int32_t* off0, int B, int ctx,
+                                const int32_t* slotbase, float* out, int64_t ldo, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pool_finalize_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, part, C, off0, ctx, slotbase,
+                     out, ldo);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ statistics pooling
 // grid (colChunks, B); block 256 = 16 row slots x 16 lanes x float4 (64 columns per block).
 // Pass 1: mean.  Pass 2: population variance as mean of squared differences to that mean

@@ -143,7 +143,7 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
     }
     if (p.Y) __syncthreads();
   }
-  if (p.Y) {
+  if (p.Y || p.pool_part) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -158,6 +158,8 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
         }
       }
     __syncthreads();
+  }
+  if (p.Y) {
     const int n = nbase + rchunk * 4;
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
@@ -169,11 +171,45 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
       if (orow >= 0 && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
     }
   }
+  if (p.pool_part) {
+    // fused statistics pooling: lane = channel; for every utterance segment inside the 64-frame
+    // tile store (sum x, sum (x - segment mean)^2) -- two passes over the LDS copy, so the merge in
+    // pool_finalize_kernel (Chan et al.) is as accurate as the reference's two-pass variance.
+    const int n = nbase + lane;
+    const bool nok = n < p.N;
+    const int my_utt = (mbase + lane < p.M) ? p.pool_row2utt[mbase + lane] : -1;   // lane r: utterance of frame r
+    const int tile64 = mbase >> 6;
+    const char* col = scratch + (lane & 3) * 4;
+    const int cchunk = lane >> 2;
+    int r = 0;
+    while (r < 64) {
+      const int b = __builtin_amdgcn_readlane(my_utt, r);
+      int re = r + 1;
+      while (re < 64 && __builtin_amdgcn_readlane(my_utt, re) == b) ++re;
+      if (b >= 0) {
+        float s1 = 0.f;
+        for (int t = r; t < re; ++t) s1 += *reinterpret_cast<const float*>(col + t * 256 + ((cchunk ^ (t & 15)) << 4));
+        const float mu = s1 / (float)(re - r);
+        float m2 = 0.f;
+        for (int t = r; t < re; ++t) {
+          const float d = *reinterpret_cast<const float*>(col + t * 256 + ((cchunk ^ (t & 15)) << 4)) - mu;
+          m2 = fmaf(d, d, m2);
+        }
+        if (nok) {
+          const int64_t slot = (int64_t)p.pool_slotbase[b] + tile64;
+          p.pool_part[(slot * 2) * p.N + n] = s1;
+          p.pool_part[(slot * 2 + 1) * p.N + n] = m2;
+        }
+      }
+      r = re;
+    }
+  }
 }
 
 // true when the vectorised LDS-staged epilogue applies to this launch
 __device__ __forceinline__ bool wide_epilogue_ok(const GemmArgs& p) {
-  return (p.N & 3) == 0 && (!p.Y || ((p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0));
+  return (p.N & 3) == 0 && (!p.Y || ((p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0)) &&
+         (!p.pool_part || p.rowmap == nullptr);
 }
 
 // Epilogue entry for a 64x64 wave tile: LDS-staged wide stores when the shape allows, scalar otherwise.

@@ -46,6 +46,14 @@ struct GemmArgs {
   int ksplit;             // 0/1 = off
   int raw;                // epilogue: store acc unchanged (scale 1, shift 0, no activation)
   float* partial;         // [ksplit][M][Npad] fp32 workspace
+  // fused statistics pooling (dense layer feeding statistics_pooling, model/pooling.py:27-52):
+  // instead of storing the activations, every 64-row wave tile writes, per channel and per
+  // utterance segment inside the tile, sum(x) and sum((x - segment mean)^2) to
+  //   pool_part[(slot * 2 + {0,1}) * N + n],  slot = pool_slotbase[b] + (row >> 6)
+  // (each slot is written exactly once -> deterministic); launch_pool_finalize merges the slots.
+  float* pool_part;
+  const int32_t* pool_row2utt;    // [M] utterance index of each row
+  const int32_t* pool_slotbase;   // [B]
 };
 
 // fp32 MFMA (v_mfma_f32_32x32x2_f32) path.  aligned: ldx == cin (or K == cin), ldx % 4 == 0,
@@ -74,6 +82,12 @@ hipError_t launch_build_rowmap(const int32_t* off0, int B, int ctx_in, int w, in
 //   rows of utterance b: [off0[b] - b*ctx, off0[b+1] - (b+1)*ctx)
 hipError_t launch_stat_pool(const float* x, int64_t ldx, int C, const int32_t* off0, int B, int ctx,
                             float* out, int64_t ldo, hipStream_t s);
+
+// row -> utterance map for the fused pooling epilogue (rows of utterance b: [off0[b]-b*ctx, off0[b+1]-(b+1)*ctx))
+hipError_t launch_build_row2utt(const int32_t* off0, int B, int ctx, int32_t* row2utt, int M, hipStream_t s);
+// finalize of the fused statistics pooling: merge the per-segment (sum, M2) pairs of each utterance
+hipError_t launch_pool_finalize(const float* part, int C, const int32_t* off0, int B, int ctx,
+                                const int32_t* slotbase, float* out, int64_t ldo, hipStream_t s);
 
 // attention scores (model/pooling.py:189-194): score[r, h] = scale * sum_d key[r, h*dk_h + d] * q[h, d]
 // (split_key) or sum_d key[r, d] * q[h, d] (no split; dk_h == dk).

@@ -159,6 +159,7 @@ struct PlanStep {
   int rowmap = -1;              // index into plan rowmaps (conv layers)
   int64_t scratch_off = -1;     // per-step scratch (im2col rows / split-K partials), released after the step
   int ksplit = 1;               // split-K slices of a small-M fp32 GEMM
+  bool fuse_pool = false;       // GEMM: emit pooling partials instead of activations; STAT_POOL: finalize only
   int64_t flops = 0, bytes = 0;
 };
 
@@ -166,10 +167,14 @@ struct xv_plan {
   xv_handle* h = nullptr;
   xv_plan_info info{};
   std::vector<int32_t> offsets;     // host copy
+  std::vector<int32_t> offsets_slotbase;
   DevBuf d_offsets;                 // [B+1]
   DevBuf d_rowmaps;                 // concatenated row maps
   std::vector<int64_t> rowmap_off;  // element offsets into d_rowmaps
   std::vector<PlanStep> steps;
+  DevBuf d_row2utt;                 // fused pooling: utterance of each pooled row
+  DevBuf d_slotbase;                // fused pooling: [B] slot base per utterance
+  int64_t pool_slots = 0;
   bool uniform_len = true;
   int uniform_L = 0;
 };
@@ -660,6 +665,34 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
   }
   std::vector<int64_t> voff_sb(h->values.size(), -1), vsize_sb(h->values.size(), 0);
 
+  // statistics pooling fused into the epilogue of the dense layer that feeds it, when that
+  // layer's output has no other reader in this plan
+  int fused_value = -1;
+  for (int o : order) {
+    const Op& op = h->ops[o];
+    if (op.kind != OP_STAT_POOL || op.in0 <= 0 || producer[op.in0] < 0) continue;
+    const Op& prod = h->ops[producer[op.in0]];
+    if (prod.kind != OP_GEMM || producer[op.in0] == node.op) continue;
+    const Layer& L = h->layers[prod.layer];
+    int readers = 0;
+    for (int o2 : order)
+      if (h->ops[o2].in0 == op.in0 || h->ops[o2].in1 == op.in0) ++readers;
+    if (readers == 1 && L.w == 1 && (L.cout & 3) == 0 && !getenv("XVEC_NO_POOL_FUSION")) fused_value = op.in0;
+  }
+  if (fused_value >= 0) {
+    const int ctx = h->values[fused_value].ctx;
+    std::vector<int32_t> slotbase(batch);
+    int64_t nslots = 0;
+    for (int b = 0; b < batch; ++b) {
+      const int r0 = frame_offsets[b] - b * ctx, r1 = frame_offsets[b + 1] - (b + 1) * ctx;
+      const int t0 = r0 >> 6, t1 = (r1 - 1) >> 6;
+      slotbase[b] = (int32_t)(nslots - t0);
+      nslots += t1 - t0 + 1;
+    }
+    p->pool_slots = nslots;
+    p->offsets_slotbase = std::move(slotbase);
+  }
+
   int64_t total_flops = 0;
   int64_t rowmap_elems = 0;
   for (size_t s = 0; s < order.size(); ++s) {
@@ -687,7 +720,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       int64_t scratch = 0;
       if (L.im2col) {
         scratch = (st.M + kSlackRows) * (int64_t)L.Kpad * 4;
-      } else if (!L.use_split) {
+      } else if (!L.use_split && op.out != fused_value) {
         st.ksplit = gemm_f32_ksplit(st.M, L.Kpad, L.Npad);
         if (st.ksplit > 1) scratch = (int64_t)st.ksplit * st.M * L.Npad * 4;
       }
@@ -699,6 +732,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       st.stage = st.to_out ? node.stage : 2;
       st.bytes = 8 * st.rows_out * h->values[op.out].cols;
     } else if (op.kind == OP_STAT_POOL || op.kind == OP_ATT_POOL) {
+      if (op.kind == OP_STAT_POOL && op.in0 == fused_value) st.fuse_pool = true;
       st.bytes = 4 * (st.rows_in * h->values[op.in0].cols + st.rows_out * h->values[op.out].cols);
       st.flops = 4 * st.rows_in * h->values[op.in0].cols;
     } else if (op.kind == OP_ATT_SCORES) {
@@ -717,7 +751,12 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     } else if (st.to_out && !node.att_weights) {
       st.out_off = -1;                   // straight into the caller's output buffer (fp32)
     } else {
-      if (want_f32[op.out] || node.att_weights) {
+      if (op.out == fused_value) {
+        st.fuse_pool = true;
+        vsize[op.out] = align_up(p->pool_slots * 2 * (int64_t)h->values[op.out].cols * 4, kAlign);
+        voff[op.out] = arena_alloc(vsize[op.out]);
+        st.out_off = voff[op.out];
+      } else if (want_f32[op.out] || node.att_weights) {
         vsize[op.out] = value_bytes(h, op.out, F0, batch);
         voff[op.out] = arena_alloc(vsize[op.out]);
         st.out_off = voff[op.out];
@@ -785,6 +824,17 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       if (e != hipSuccess) return bail(e, "build_rowmap");
     }
   }
+  if (fused_value >= 0) {
+    const int ctx = h->values[fused_value].ctx;
+    const int64_t rows = value_rows(h, fused_value, F0, batch);
+    if ((e = p->d_row2utt.alloc((size_t)rows * 4)) != hipSuccess) return bail(e, "hipMalloc(row2utt)");
+    if ((e = p->d_slotbase.alloc((size_t)batch * 4)) != hipSuccess) return bail(e, "hipMalloc(slotbase)");
+    if ((e = hipMemcpyAsync(p->d_slotbase.p, p->offsets_slotbase.data(), (size_t)batch * 4, hipMemcpyHostToDevice, s)) != hipSuccess)
+      return bail(e, "hipMemcpyAsync(slotbase)");
+    if ((e = launch_build_row2utt(static_cast<const int32_t*>(p->d_offsets.p), batch, ctx,
+                                  static_cast<int32_t*>(p->d_row2utt.p), (int)rows, s)) != hipSuccess)
+      return bail(e, "build_row2utt");
+  }
   if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail(e, "hipStreamSynchronize");
   *out = p;
   return XV_OK;
@@ -802,6 +852,8 @@ void xv_plan_destroy(xv_plan* p) {
     DeviceGuard g(p->h->device);
     p->d_offsets.release();
     p->d_rowmaps.release();
+    p->d_row2utt.release();
+    p->d_slotbase.release();
   }
   delete p;
 }
@@ -871,6 +923,12 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         a.alpha = (a.act == ACT_PRELU) ? L.d_alpha() : nullptr;
         a.rowmap = st.rowmap >= 0 ? static_cast<const int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.rowmap] : nullptr;
         a.Y = optr; a.ldy = L.cout;
+        if (st.fuse_pool) {                 // statistics pooling partials instead of activations
+          a.Y = nullptr;
+          a.pool_part = reinterpret_cast<float*>(ws + st.out_off);
+          a.pool_row2utt = static_cast<const int32_t*>(p->d_row2utt.p);
+          a.pool_slotbase = static_cast<const int32_t*>(p->d_slotbase.p);
+        }
         if (st.out_sb_off >= 0) {
           a.Ysb = ws + st.out_sb_off;
           a.ldsb = sb_ld(L.cout);
@@ -906,6 +964,11 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
       }
       case OP_STAT_POOL: {
         const Value& vi = h->values[op.in0];
+        if (st.fuse_pool) {
+          XV_HIP(h, launch_pool_finalize(in_ptr(st.in0_off), vi.cols, off, B, vi.ctx,
+                                         static_cast<const int32_t*>(p->d_slotbase.p), optr, 2 * vi.cols, s));
+          break;
+        }
         XV_HIP(h, launch_stat_pool(in_ptr(st.in0_off), vi.cols, vi.cols, off, B, vi.ctx, optr, 2 * vi.cols, s));
         break;
       }
