@@ -47,6 +47,24 @@ def parse_args():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel, precision, args):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
+    command (profiles/<round>/traffic.json; FETCH_SIZE/WRITE_SIZE need their own profiler runs, so
+    they cannot be sampled inside the timed region).  None when no matching profile exists."""
+    if precision != "bf16x3" or args.varlen or args.pooling != "statistics_pooling" or args.batch != 256 or args.frames != 300:
+        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                k = json.load(f)["kernels"].get(kernel)
+            if k:
+                return k["traffic_bytes"]
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def cpu_baseline(weights, params, dim, frames, budget_s):
     """oracle/ref_torch.py on this box's host cores: 1 thread, 1 utterance per call."""
     import torch
@@ -150,11 +168,14 @@ def main():
             tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             peak = PEAK_TFLOPS[precision]
             roof = {"kernel": dom["name"], "bound": "mfma", "achieved": round(tf, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": pmc_traffic(dom["name"], precision, args),
                     "launch_ms": round(dom["ms"], 4),
                     "hbm_frac_algorithmic": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            roof["algorithmic_bytes"] = dom["bytes"]
             if precision == "bf16x3":
-                roof["note"] = "3 bf16 MFMAs per algorithmic product: issued-MFMA fraction = 3 x frac"
+                roof["mfma_issue_frac"] = round(3 * tf / peak, 4)
+                roof["note"] = ("bf16x3: 3 bf16 MFMAs per algorithmic product, so the ceiling of `frac` is 1/3; "
+                                "mfma_issue_frac = issued MFMA FLOPs / bf16 dense peak")
         flops_step = float(info["flops"])
         result = {
             "metric": "utterances/sec x-vector extraction (30-dim x 300-frame)",

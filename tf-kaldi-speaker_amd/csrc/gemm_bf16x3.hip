@@ -464,7 +464,7 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
   }
   const int w = a.K / a.cin > 0 && a.ldsbx == a.cin ? a.K / a.cin : 1;   // taps (dense: 1)
   const bool taps_ok = w <= 8 && (a.Kpad >> 5) % w == 0;
-  if (taps_ok && (force == 256 || (force == 0 && a.M >= 4096))) {
+  if (taps_ok && force == 256) {   // A/B variant only: measured slower than the 128x128 DMA kernel (profiles/)
     const int nMt = (a.M + PBM - 1) / PBM, nNt = a.Npad / BN;
     hipLaunchKernelGGL(gemm_bf16x3_pipe_kernel, dim3(nMt * nNt), dim3(PNT), smempipe, s, a, nMt, nNt, w);
     return hipGetLastError();

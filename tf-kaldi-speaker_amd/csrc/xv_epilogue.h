@@ -175,30 +175,51 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
     // fused statistics pooling: lane = channel; for every utterance segment inside the 64-frame
     // tile store (sum x, sum (x - segment mean)^2) -- two passes over the LDS copy, so the merge in
     // pool_finalize_kernel (Chan et al.) is as accurate as the reference's two-pass variance.
-    const int n = nbase + lane;
+    // Lane map: cq = lane & 15 -> columns 4cq..4cq+3 (one 16-byte LDS chunk), rg = lane >> 4 -> frames
+    // t == rg (mod 4); the four frame groups are combined with two xor-shuffles.
+    const int cq = lane & 15, rg = lane >> 4;
+    const int n = nbase + 4 * cq;
     const bool nok = n < p.N;
     const int my_utt = (mbase + lane < p.M) ? p.pool_row2utt[mbase + lane] : -1;   // lane r: utterance of frame r
     const int tile64 = mbase >> 6;
-    const char* col = scratch + (lane & 3) * 4;
-    const int cchunk = lane >> 2;
+    auto row4 = [&](int t) -> f32x4 {
+      return *reinterpret_cast<const f32x4*>(scratch + t * 256 + ((cq ^ (t & 15)) << 4));
+    };
+    auto groups_sum = [&](f32x4 v) -> f32x4 {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] += __shfl_xor(v[i], 16, 64);
+        v[i] += __shfl_xor(v[i], 32, 64);
+      }
+      return v;
+    };
     int r = 0;
     while (r < 64) {
       const int b = __builtin_amdgcn_readlane(my_utt, r);
       int re = r + 1;
       while (re < 64 && __builtin_amdgcn_readlane(my_utt, re) == b) ++re;
       if (b >= 0) {
-        float s1 = 0.f;
-        for (int t = r; t < re; ++t) s1 += *reinterpret_cast<const float*>(col + t * 256 + ((cchunk ^ (t & 15)) << 4));
-        const float mu = s1 / (float)(re - r);
-        float m2 = 0.f;
-        for (int t = r; t < re; ++t) {
-          const float d = *reinterpret_cast<const float*>(col + t * 256 + ((cchunk ^ (t & 15)) << 4)) - mu;
-          m2 = fmaf(d, d, m2);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s1 = z;
+        for (int t0 = r & ~3; t0 < re; t0 += 4) {
+          const int t = t0 + rg;
+          if (t >= r && t < re) s1 += row4(t);
         }
-        if (nok) {
+        s1 = groups_sum(s1);
+        const f32x4 mu = s1 / (float)(re - r);
+        f32x4 m2 = z;
+        for (int t0 = r & ~3; t0 < re; t0 += 4) {
+          const int t = t0 + rg;
+          if (t >= r && t < re) {
+            const f32x4 d = row4(t) - mu;
+            m2 += d * d;
+          }
+        }
+        m2 = groups_sum(m2);
+        if (nok && rg == 0) {
           const int64_t slot = (int64_t)p.pool_slotbase[b] + tile64;
-          p.pool_part[(slot * 2) * p.N + n] = s1;
-          p.pool_part[(slot * 2 + 1) * p.N + n] = m2;
+          *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2) * p.N + n) = s1;
+          *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2 + 1) * p.N + n) = m2;
         }
       }
       r = re;
