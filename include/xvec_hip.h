@@ -49,8 +49,9 @@ typedef enum {
   XV_ERR_TOO_SHORT = -7       /* an utterance has fewer frames than the node needs   */
 } xv_status;
 
-/* network_type: model/trainer.py:100-110 (only "tdnn" is on the hot path this round) */
-enum { XV_NET_TDNN = 0 };
+/* network_type: model/trainer.py:100-110.  "tdnn" = model/tdnn.py:10-181, "extended_tdnn" = the
+ * 10-frame-layer variant model/tdnn.py:343-591 (variable scope "etdnn", conv1d kernels [w,cin,cout]) */
+enum { XV_NET_TDNN = 0, XV_NET_ETDNN = 1 };
 /* pooling_type: model/pooling.py:14-23 */
 enum { XV_POOL_STATISTICS = 0, XV_POOL_SELF_ATTENTION = 1 };
 /* network_relu_type: model/tdnn.py:28-33 */
@@ -81,7 +82,7 @@ typedef struct {
   int32_t feature_norm;             /* endpoints["output"] = l2_scaling(output)            */
   float feature_scaling_factor;
   /* self-attention (model/pooling.py:55-240) */
-  int32_t att_key_input;            /* 3/4/5: endpoints["tdnn<N>_relu"]                    */
+  int32_t att_key_input;            /* N of endpoints["tdnn<N>_relu"]: a frame layer at full context (tdnn: 3..5, etdnn: 7..10) */
   int32_t att_value_input;
   int32_t att_num_key_layers;       /* len(att_key_num_nodes), 1..XV_MAX_ATT_LAYERS        */
   int32_t att_key_num_nodes[XV_MAX_ATT_LAYERS];
@@ -130,8 +131,8 @@ int xv_finalize(xv_handle* h);
  * Returns the id (>= 0) or XV_ERR_INVALID for a name the graph does not define. */
 int xv_node_id(const xv_handle* h, const char* endpoint_name);
 
-/* Number of frames of temporal context the node consumes (14 for everything at or past
- * tdnn3); an utterance needs more than this many frames. */
+/* Number of frames of temporal context the node consumes (tdnn: 14 for everything at or past
+ * tdnn3; etdnn: 22 at or past tdnn7); an utterance needs more than this many frames. */
 int xv_node_context(const xv_handle* h, int node_id);
 
 /* Batch geometry.  `frame_offsets` (host, B+1 ascending int32, [0] == 0) delimits the B

@@ -38,11 +38,21 @@ class TorchTdnn(object):
         self.params = params
         self.dtype = dtype
         self.w = {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v))).to(dtype) for k, v in weights.items()}
-        # conv kernels [1,k,cin,cout] (HWIO) -> conv1d weight [cout,cin,k]   (model/tdnn.py:42-47)
+        ntype = _get(params, "network_type")
+        if ntype == "tdnn":                                # model/tdnn.py:36-181
+            self.scope, self.widths, self.seg = "tdnn", (5, 5, 7, 1, 1), (6, 7)
+        elif ntype == "extended_tdnn":                     # model/tdnn.py:343-591
+            self.scope, self.widths, self.seg = "etdnn", (5, 1, 5, 1, 7, 1, 9, 1, 1, 1), (12, 13)
+        else:
+            raise NotImplementedError("Not implement %s network" % ntype)
+        # conv kernels [1,k,cin,cout] (conv2d HWIO) or [k,cin,cout] (conv1d) -> conv1d weight [cout,cin,k]
         self.conv = {}
-        for i in (1, 2, 3):
-            k = self.w["tdnn/tdnn%d_conv/kernel" % i]
-            self.conv[i] = k[0].permute(2, 1, 0).contiguous()
+        for i, wd in enumerate(self.widths, start=1):
+            if wd > 1:
+                k = self.w["%s/tdnn%d_conv/kernel" % (self.scope, i)]
+                if k.dim() == 4:
+                    k = k[0]
+                self.conv[i] = k.permute(2, 1, 0).contiguous()
 
     def _bn(self, x, scope):
         w = self.w
@@ -57,8 +67,8 @@ class TorchTdnn(object):
             return F.leaky_relu(x, LRELU_ALPHA)
         return F.relu(x)
 
-    def _dense_block(self, x, name, kind, ep, scope="tdnn/attention"):
-        base = "%s/%s" % (scope, name)
+    def _dense_block(self, x, name, kind, ep, scope=None):
+        base = "%s/%s" % (scope or (self.scope + "/attention"), name)
         x = F.linear(x, self.w["%s/%s_dense/kernel" % (base, name)].t(), self.w["%s/%s_dense/bias" % (base, name)])
         ep["%s_dense" % name] = x
         if kind == 2:
@@ -92,7 +102,7 @@ class TorchTdnn(object):
                 value = self._dense_block(value, "att_value%d" % i, 2, ep)
             value = self._dense_block(value, "att_value%d" % (len(vn) - 1), int(_get(p, "att_value_network_type")), ep)
         h = int(_get(p, "att_num_heads"))
-        q = self.w["tdnn/attention/query"]
+        q = self.w[self.scope + "/attention/query"]
         b, l, dv = value.shape
         dk = key.shape[-1]
         if _get(p, "att_split_key"):
@@ -118,9 +128,9 @@ class TorchTdnn(object):
         att = torch.cat([mean, var.sqrt()], dim=1)
         ep["att_output_before_nonlinear"] = att
         if _get(p, "att_apply_nonlinear"):
-            att = self._bn(att, "tdnn/attention/att_post_bn")
+            att = self._bn(att, self.scope + "/attention/att_post_bn")
             ep["att_post_bn"] = att
-            att = self._act(att, "tdnn/attention/att_post_relu")
+            att = self._act(att, self.scope + "/attention/att_post_relu")
             ep["att_post_relu"] = att
         return att
 
@@ -130,25 +140,19 @@ class TorchTdnn(object):
         p = self.params
         ep = OrderedDict()
         x = torch.as_tensor(np.ascontiguousarray(features)).to(self.dtype)
-        x = x.transpose(1, 2)                              # [b,d,l] for conv1d
-        for i in (1, 2, 3):                                # model/tdnn.py:40-96
-            s = "tdnn/tdnn%d" % i
-            if x.shape[2] < self.conv[i].shape[2]:
-                x = x.new_zeros((x.shape[0], self.conv[i].shape[0], 0))
+        sc = self.scope
+        for i, wd in enumerate(self.widths, start=1):      # model/tdnn.py:40-130 / :377-540
+            s = "%s/tdnn%d" % (sc, i)
+            if wd > 1:
+                xt = x.transpose(1, 2)                     # [b,c,l] for conv1d
+                if xt.shape[2] < wd:
+                    x = x.new_zeros((x.shape[0], 0, self.conv[i].shape[0]))
+                else:
+                    x = F.conv1d(xt, self.conv[i], self.w[s + "_conv/bias"]).transpose(1, 2)
+                ep["tdnn%d_conv" % i] = x
             else:
-                x = F.conv1d(x, self.conv[i], self.w[s + "_conv/bias"])
-            y = x.transpose(1, 2)
-            ep["tdnn%d_conv" % i] = y
-            y = self._bn(y, s + "_bn")
-            ep["tdnn%d_bn" % i] = y
-            y = self._act(y, s + "_relu")
-            ep["tdnn%d_relu" % i] = y
-            x = y.transpose(1, 2)
-        x = x.transpose(1, 2)
-        for i in (4, 5):                                   # model/tdnn.py:99-130
-            s = "tdnn/tdnn%d" % i
-            x = F.linear(x, self.w[s + "_dense/kernel"].t(), self.w[s + "_dense/bias"])
-            ep["tdnn%d_dense" % i] = x
+                x = F.linear(x, self.w[s + "_dense/kernel"].t(), self.w[s + "_dense/bias"])
+                ep["tdnn%d_dense" % i] = x
             x = self._bn(x, s + "_bn")
             ep["tdnn%d_bn" % i] = x
             x = self._act(x, s + "_relu")
@@ -161,20 +165,21 @@ class TorchTdnn(object):
         else:
             raise NotImplementedError("Not implement %s pooling" % ptype)
         ep["pooling"] = x
-        x = F.linear(x, self.w["tdnn/tdnn6_dense/kernel"].t(), self.w["tdnn/tdnn6_dense/bias"])
-        ep["tdnn6_dense"] = x
-        x = self._bn(x, "tdnn/tdnn6_bn")
-        ep["tdnn6_bn"] = x
-        x = self._act(x, "tdnn/tdnn6_relu")
-        ep["tdnn6_relu"] = x
-        x = F.linear(x, self.w["tdnn/tdnn7_dense/kernel"].t(), self.w["tdnn/tdnn7_dense/bias"])
-        ep["tdnn7_dense"] = x
+        a, b = self.seg
+        x = F.linear(x, self.w["%s/tdnn%d_dense/kernel" % (sc, a)].t(), self.w["%s/tdnn%d_dense/bias" % (sc, a)])
+        ep["tdnn%d_dense" % a] = x
+        x = self._bn(x, "%s/tdnn%d_bn" % (sc, a))
+        ep["tdnn%d_bn" % a] = x
+        x = self._act(x, "%s/tdnn%d_relu" % (sc, a))
+        ep["tdnn%d_relu" % a] = x
+        x = F.linear(x, self.w["%s/tdnn%d_dense/kernel" % (sc, b)].t(), self.w["%s/tdnn%d_dense/bias" % (sc, b)])
+        ep["tdnn%d_dense" % b] = x
         if not _get(p, "last_layer_no_bn", False):
-            x = self._bn(x, "tdnn/tdnn7_bn")
-            ep["tdnn7_bn"] = x
+            x = self._bn(x, "%s/tdnn%d_bn" % (sc, b))
+            ep["tdnn%d_bn" % b] = x
         if not _get(p, "last_layer_linear", False):
-            x = self._act(x, "tdnn/tdnn7_relu")
-            ep["tdnn7_relu"] = x
+            x = self._act(x, "%s/tdnn%d_relu" % (sc, b))
+            ep["tdnn%d_relu" % b] = x
         ep["output"] = x
         if _get(p, "feature_norm", False):                 # model/trainer.py:400-403
             sq = (x * x).sum(-1, keepdim=True)

@@ -124,6 +124,35 @@ def test_attention_variants_small(kw, precision):
     tr.close()
 
 
+@pytest.mark.parametrize("pooling", ["statistics_pooling", "self_attention"])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_extended_tdnn_every_endpoint(precision, pooling):
+    """network_type "extended_tdnn" (model/tdnn.py:343-591): conv1d k=5,5,7,9 interleaved with dense,
+    context 22, segment layers tdnn12/tdnn13.  Full-width graph on a [2,45,30] batch."""
+    from tf_kaldi_speaker_amd import synth
+    params = dict(synth.TDNN_ATT_PARAMS if pooling == "self_attention" else synth.TDNN_STAT_PARAMS,
+                  network_type="extended_tdnn", embedding_node="tdnn12_dense")
+    if pooling == "self_attention":
+        params.update(att_key_input="tdnn9_relu", att_value_input="tdnn10_relu", att_key_num_nodes=[256, 128], att_num_heads=2)
+    weights = synth.synth_weights(params, 30, seed=6)
+    if "etdnn/attention/query" in weights:
+        weights["etdnn/attention/query"] = weights["etdnn/attention/query"] * 100.0
+    feats = np.stack(synth.synth_features(2, 45, 30, seed=14))
+    _, ep = ref_numpy.entire_network(feats, weights, params)
+    assert ep["tdnn7_relu"].shape == (2, 23, 512) and ep["tdnn12_dense"].shape == (2, 512)
+    tr, _ = _trainer(params, weights, 30, precision)
+    for name, ref in ep.items():
+        tr.set_embedding(name)
+        got = tr.predict(feats)
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        err = _rel(got, ref)
+        _note("etdnn_" + pooling[:4], precision, name, err)
+        assert err <= TOL, (name, err)
+    with pytest.raises(ValueError):
+        tr.predict(np.zeros((22, 30), np.float32))                  # context is 22 frames
+    tr.close()
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_xvector_300_frames(stat_model, precision):
     """BASELINE config 2 shape (30-dim x 300 frames), small batch, tdnn6_dense."""

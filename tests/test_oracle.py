@@ -73,6 +73,24 @@ def test_numpy_and_torch_restatements_agree(pooling, kw):
         assert err < 2e-6, (k, err)
 
 
+@pytest.mark.parametrize("pooling", ["statistics_pooling", "self_attention"])
+def test_extended_tdnn_restatements_agree(pooling):
+    """model/tdnn.py:343-591: 10 frame layers (conv1d k=5,5,7,9 + dense), tdnn12/tdnn13 segment layers."""
+    p = _small_params(pooling, network_type="extended_tdnn", embedding_node="tdnn12_dense")
+    if pooling == "self_attention":
+        p.update(att_key_input="tdnn8_relu", att_value_input="tdnn10_relu")
+    w = synth.synth_weights(p, 7, seed=3, channels=32)
+    assert w["etdnn/tdnn7_conv/kernel"].shape == (9, 32, 32)            # conv1d kernels are rank 3
+    feats = np.stack(synth.synth_features(2, 40, 7, seed=5))
+    _, ep = ref_numpy.entire_network(feats, w, p)
+    ep_t = ref_torch.TorchTdnn(w, p).forward(feats)
+    assert list(ep.keys()) == list(ep_t.keys())
+    assert ep["tdnn7_relu"].shape == (2, 40 - 22, 32) and "tdnn13_relu" in ep and "tdnn11_dense" not in ep
+    for k in ep:
+        a, b = ep[k], ep_t[k].numpy().astype(np.float64)
+        assert np.linalg.norm(a - b) / max(np.linalg.norm(a), 1e-30) < 2e-6, k
+
+
 def test_full_size_tdnn_restatements_agree():
     p = dict(synth.TDNN_STAT_PARAMS)
     w = synth.synth_weights(p, 30, seed=0)

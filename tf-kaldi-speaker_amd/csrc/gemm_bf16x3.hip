@@ -207,13 +207,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
     int cb_next = cb, j_next = j + 1;
     if (j_next == w) { j_next = 0; cb_next = cb + 1; }
     if (s + 1 < nsteps && !(diag & 4)) {   // diag bit2: no weight DMA in the loop (timing only)
-      const int kb = j_next * ncb + cb_next;
+      const int kb = (diag & 32) ? 0 : j_next * ncb + cb_next;   // diag bit5: always the same (L2-hot) source tile
 #pragma unroll
       for (int q = 0; q < 4; ++q) dma_b(kb, (s + 1) & 1, wave + 4 * q);
     }
     if (cb + 1 < ncb && !(diag & 8)) {     // diag bit3: no slab DMA in the loop (timing only)
       const int gend = min((j + 1) * gps, ngroups);
-      for (int g = j * gps + wave; g < gend; g += 4) dma_a(cb + 1, (cb + 1) & 1, g);
+      for (int g = j * gps + wave; g < gend; g += 4) dma_a((diag & 32) ? 0 : cb + 1, (cb + 1) & 1, g);
     }
 
     const char* ab = As + (cb & 1) * DA_BYTES;
@@ -463,8 +463,8 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int w = a.K / a.cin > 0 && a.ldsbx == a.cin ? a.K / a.cin : 1;   // taps (dense: 1)
-  const bool taps_ok = w <= 8 && (a.Kpad >> 5) % w == 0;
-  if (taps_ok && force == 256) {   // A/B variant only: measured slower than the 128x128 DMA kernel (profiles/)
+  const bool taps_ok = w <= 9 && (a.Kpad >> 5) % w == 0;   // slab halo: 128 + w - 1 <= DA_ROWS (136)
+  if (taps_ok && w <= 8 && force == 256) {   // A/B variant only: measured slower than the 128x128 DMA kernel (profiles/)
     const int nMt = (a.M + PBM - 1) / PBM, nNt = a.Npad / BN;
     hipLaunchKernelGGL(gemm_bf16x3_pipe_kernel, dim3(nMt * nNt), dim3(PNT), smempipe, s, a, nMt, nNt, w);
     return hipGetLastError();

@@ -134,6 +134,7 @@ struct xv_handle {
   // attention extras
   DevBuf query;                 // [H, dk_h]
   int att_dk_h = 0, att_dk = 0, att_dv = 0;
+  int final_ctx = 14;           // temporal context of the pooled frames (tdnn 14, etdnn 22)
   std::string post_bn_scope, post_alpha_name;
   DevBuf post_vec;              // [scale | shift | alpha] each pool_dim floats
   int pool_dim = 0;
@@ -233,13 +234,15 @@ int act_of(const xv_model_desc& d) {
 // adds layer + op + value + nodes; returns the output value id
 int add_layer(xv_handle* h, const std::string& var_scope, const std::string& ep_prefix, bool conv, int w,
               int cin, int cout, bool has_bn, int act, int in_value, bool frame_level, int ctx_out,
-              const char* tanh_ep = nullptr) {
+              int kernel_rank = 4) {
   Layer L;
   const std::string kind = conv ? "_conv" : "_dense";
   L.kernel_name = var_scope + kind + "/kernel";
   L.bias_name = var_scope + kind + "/bias";
   L.w = w; L.cin = cin; L.cout = cout; L.has_bn = has_bn; L.act = act;
-  if (conv) expect(h, L.kernel_name, {1, w, cin, cout}); else expect(h, L.kernel_name, {cin, cout});
+  if (conv && kernel_rank == 4) expect(h, L.kernel_name, {1, w, cin, cout});      // tf.layers.conv2d (1,w): HWIO
+  else if (conv) expect(h, L.kernel_name, {w, cin, cout});                         // tf.layers.conv1d
+  else expect(h, L.kernel_name, {cin, cout});
   expect(h, L.bias_name, {cout});
   L.ep[ST_AFFINE] = ep_prefix + kind;
   if (has_bn) {
@@ -254,7 +257,6 @@ int add_layer(xv_handle* h, const std::string& var_scope, const std::string& ep_
       expect(h, L.alpha_name, {cout});
     }
   }
-  (void)tanh_ep;
   const int li = (int)h->layers.size();
   h->layers.push_back(std::move(L));
   Value v; v.frame_level = frame_level; v.ctx = ctx_out; v.cols = cout;
@@ -284,30 +286,48 @@ void add_node(xv_handle* h, const std::string& name, int op, int stage, bool att
   h->nodes.push_back(n);
 }
 
-// Build the predict graph of model/tdnn.py:36-181 for `desc`.
+// Build the predict graph for `desc`: model/tdnn.py:36-181 (tdnn) or :343-591 (etdnn).
 int build_graph(xv_handle* h) {
   const xv_model_desc& d = h->desc;
   const int C = d.channels, act = act_of(d);
   h->values.clear();
   Value in; in.frame_level = true; in.ctx = 0; in.cols = d.feat_dim;
   h->values.push_back(in);   // value 0 = network input
-  int v = 0;
-  v = add_layer(h, "tdnn/tdnn1", "tdnn1", true, 5, d.feat_dim, C, true, act, v, true, 4);
-  v = add_layer(h, "tdnn/tdnn2", "tdnn2", true, 5, C, C, true, act, v, true, 8);
-  const int v3 = v = add_layer(h, "tdnn/tdnn3", "tdnn3", true, 7, C, C, true, act, v, true, 14);
-  const int v4 = v = add_layer(h, "tdnn/tdnn4", "tdnn4", false, 1, C, C, true, act, v, true, 14);
-  const int v5 = v = add_layer(h, "tdnn/tdnn5", "tdnn5", false, 1, C, d.num_nodes_pooling_layer, true, act, v, true, 14);
+  // frame-level layer table: kernel width per layer (1 = dense); the last one feeds the pooling
+  static const int kTdnn[] = {5, 5, 7, 1, 1};
+  static const int kEtdnn[] = {5, 1, 5, 1, 7, 1, 9, 1, 1, 1};
+  const bool et = d.network_type == XV_NET_ETDNN;
+  const int* widths = et ? kEtdnn : kTdnn;
+  const int nframe = et ? 10 : 5;
+  const std::string scope = et ? "etdnn/" : "tdnn/";
+  std::vector<int> frame_value(nframe + 1, -1);   // value id of layer i's output (1-based)
+  int v = 0, ctx = 0, cin = d.feat_dim;
+  for (int i = 1; i <= nframe; ++i) {
+    const int w = widths[i - 1];
+    ctx += w - 1;
+    const int cout = (i == nframe) ? d.num_nodes_pooling_layer : C;
+    char nm[16];
+    snprintf(nm, sizeof(nm), "tdnn%d", i);
+    v = add_layer(h, scope + nm, nm, w > 1, w, cin, cout, true, act, v, true, ctx, et ? 3 : 4);
+    frame_value[i] = v;
+    cin = cout;
+  }
+  h->final_ctx = ctx;
+  const int v_last = v;
 
   int pooled;
   if (d.pooling_type == XV_POOL_STATISTICS) {
     h->pool_dim = 2 * d.num_nodes_pooling_layer;
-    pooled = add_simple_op(h, OP_STAT_POOL, v5, -1, false, 0, h->pool_dim);
+    pooled = add_simple_op(h, OP_STAT_POOL, v_last, -1, false, 0, h->pool_dim);
     add_node(h, "pooling", (int)h->ops.size() - 1, -1);
   } else if (d.pooling_type == XV_POOL_SELF_ATTENTION) {
-    auto pick = [&](int which) { return which == 3 ? v3 : (which == 4 ? v4 : (which == 5 ? v5 : -1)); };
+    auto pick = [&](int which) {     // a frame layer whose output already has the full temporal context
+      if (which < 1 || which > nframe) return -1;
+      return h->values[frame_value[which]].ctx == ctx ? frame_value[which] : -1;
+    };
     int key = pick(d.att_key_input), val = pick(d.att_value_input);
     if (key < 0 || val < 0)
-      return fail(h, XV_ERR_UNSUPPORTED, "att_key_input/att_value_input must be tdnn3_relu, tdnn4_relu or tdnn5_relu");
+      return fail(h, XV_ERR_UNSUPPORTED, "att_key_input/att_value_input must be a tdnn<N>_relu at full temporal context");
     if (d.att_num_key_layers < 1 || d.att_num_key_layers > XV_MAX_ATT_LAYERS || d.att_num_value_layers < 0 ||
         d.att_num_value_layers > XV_MAX_ATT_LAYERS)
       return fail(h, XV_ERR_INVALID, "attention: bad number of key/value layers");
@@ -315,18 +335,18 @@ int build_graph(xv_handle* h) {
       bn = kind == 2;
       a = (kind == 1 || kind == 2) ? act : (kind == 3 ? ACT_TANH : ACT_NONE);
     };
-    const std::string base = "tdnn/attention/";
+    const std::string base = scope + "attention/";
     for (int i = 0; i < d.att_num_key_layers; ++i) {                       // model/pooling.py:100-116
       bool bn; int a;
       kind_to(i < d.att_num_key_layers - 1 ? 2 : d.att_key_network_type, bn, a);
       char nm[32]; snprintf(nm, sizeof(nm), "att_key%d", i);
-      key = add_layer(h, base + nm + "/" + nm, nm, false, 1, h->values[key].cols, d.att_key_num_nodes[i], bn, a, key, true, 14);
+      key = add_layer(h, base + nm + "/" + nm, nm, false, 1, h->values[key].cols, d.att_key_num_nodes[i], bn, a, key, true, ctx);
     }
     for (int i = 0; i < d.att_num_value_layers; ++i) {                     // model/pooling.py:119-135
       bool bn; int a;
       kind_to(i < d.att_num_value_layers - 1 ? 2 : d.att_value_network_type, bn, a);
       char nm[32]; snprintf(nm, sizeof(nm), "att_value%d", i);
-      val = add_layer(h, base + nm + "/" + nm, nm, false, 1, h->values[val].cols, d.att_value_num_nodes[i], bn, a, val, true, 14);
+      val = add_layer(h, base + nm + "/" + nm, nm, false, 1, h->values[val].cols, d.att_value_num_nodes[i], bn, a, val, true, ctx);
     }
     const int H = d.att_num_heads;
     h->att_dk = h->values[key].cols;
@@ -335,18 +355,18 @@ int build_graph(xv_handle* h) {
     if (d.att_split_key && h->att_dk % H) return fail(h, XV_ERR_INVALID, "key dim %d not divisible by %d heads", h->att_dk, H);
     if (d.att_split_value && h->att_dv % H) return fail(h, XV_ERR_INVALID, "value dim %d not divisible by %d heads", h->att_dv, H);
     h->att_dk_h = d.att_split_key ? h->att_dk / H : h->att_dk;
-    expect(h, "tdnn/attention/query", {H, h->att_dk_h});
-    const int sc = add_simple_op(h, OP_ATT_SCORES, key, -1, true, 14, H);
-    const int sm = add_simple_op(h, OP_ATT_SOFTMAX, sc, -1, true, 14, H);
+    expect(h, scope + "attention/query", {H, h->att_dk_h});
+    const int sc = add_simple_op(h, OP_ATT_SCORES, key, -1, true, ctx, H);
+    const int sm = add_simple_op(h, OP_ATT_SOFTMAX, sc, -1, true, ctx, H);
     add_node(h, "attention_weights", (int)h->ops.size() - 1, -1, true);
     h->pool_dim = 2 * (d.att_split_value ? h->att_dv : h->att_dv * H);
     pooled = add_simple_op(h, OP_ATT_POOL, val, sm, false, 0, h->pool_dim);
     add_node(h, "att_output_before_nonlinear", (int)h->ops.size() - 1, -1);
     if (d.att_apply_nonlinear) {                                           // model/pooling.py:222-229
-      h->post_bn_scope = "tdnn/attention/att_post_bn";
+      h->post_bn_scope = scope + "attention/att_post_bn";
       expect_bn(h, h->post_bn_scope, h->pool_dim);
       if (act == ACT_PRELU) {
-        h->post_alpha_name = "tdnn/attention/att_post_relu/alpha";
+        h->post_alpha_name = scope + "attention/att_post_relu/alpha";
         expect(h, h->post_alpha_name, {h->pool_dim});
       }
       pooled = add_simple_op(h, OP_AFFINE_ACT, pooled, -1, false, 0, h->pool_dim);
@@ -357,8 +377,12 @@ int build_graph(xv_handle* h) {
   } else {
     return fail(h, XV_ERR_UNSUPPORTED, "Not implement pooling_type %d", d.pooling_type);
   }
-  v = add_layer(h, "tdnn/tdnn6", "tdnn6", false, 1, h->pool_dim, C, true, act, pooled, false, 0);
-  v = add_layer(h, "tdnn/tdnn7", "tdnn7", false, 1, C, d.num_nodes_last_layer, !d.last_layer_no_bn,
+  // segment-level layers: tdnn6/tdnn7 (model/tdnn.py:137-179) or tdnn12/tdnn13 (:547-589)
+  char s1[16], s2[16];
+  snprintf(s1, sizeof(s1), "tdnn%d", et ? 12 : 6);
+  snprintf(s2, sizeof(s2), "tdnn%d", et ? 13 : 7);
+  v = add_layer(h, scope + s1, s1, false, 1, h->pool_dim, C, true, act, pooled, false, 0);
+  v = add_layer(h, scope + s2, s2, false, 1, C, d.num_nodes_last_layer, !d.last_layer_no_bn,
                 d.last_layer_linear ? ACT_NONE : act, v, false, 0);
   if (d.feature_norm) {                                                     // model/trainer.py:400-403
     add_simple_op(h, OP_L2_SCALE, v, -1, false, 0, d.num_nodes_last_layer);
@@ -466,8 +490,8 @@ int xv_create(const xv_model_desc* desc, int device, xv_handle** out) {
   if (desc->struct_size != (int32_t)sizeof(xv_model_desc))
     return fail(nullptr, XV_ERR_INVALID, "xv_create: xv_model_desc size %d != %zu (ABI mismatch)", desc->struct_size,
                 sizeof(xv_model_desc));
-  if (desc->network_type != XV_NET_TDNN)
-    return fail(nullptr, XV_ERR_UNSUPPORTED, "Not implement network_type %d (only tdnn)", desc->network_type);
+  if (desc->network_type != XV_NET_TDNN && desc->network_type != XV_NET_ETDNN)
+    return fail(nullptr, XV_ERR_UNSUPPORTED, "Not implement network_type %d (tdnn, extended_tdnn)", desc->network_type);
   if (desc->feat_dim < 1 || desc->channels < 1 || desc->num_nodes_pooling_layer < 1 || desc->num_nodes_last_layer < 1)
     return fail(nullptr, XV_ERR_INVALID, "xv_create: non-positive layer width");
   if (desc->precision != XV_PREC_F32 && desc->precision != XV_PREC_BF16X3)
@@ -537,7 +561,7 @@ int xv_finalize(xv_handle* h) {
     if (rc != XV_OK) return rc;
   }
   if (h->desc.pooling_type == XV_POOL_SELF_ATTENTION) {
-    const auto& q = T(h, "tdnn/attention/query").data;
+    const auto& q = T(h, std::string(h->desc.network_type == XV_NET_ETDNN ? "etdnn/" : "tdnn/") + "attention/query").data;
     XV_HIP(h, h->query.alloc(q.size() * sizeof(float)));
     XV_HIP(h, hipMemcpy(h->query.p, q.data(), q.size() * sizeof(float), hipMemcpyHostToDevice));
     if (h->desc.att_apply_nonlinear) {
@@ -571,7 +595,7 @@ int xv_node_context(const xv_handle* h, int node_id) {
   if (!h || node_id < 0 || node_id >= (int)h->nodes.size()) return XV_ERR_INVALID;
   const Op& op = h->ops[h->nodes[node_id].op];
   const Value& v = h->values[op.out];
-  return v.frame_level ? v.ctx : 14;
+  return v.frame_level ? v.ctx : h->final_ctx;
 }
 
 int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int node_id, void* stream, xv_plan** out) {
@@ -982,8 +1006,8 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
       }
       case OP_ATT_SOFTMAX: {
         float* sc = reinterpret_cast<float*>(ws + st.out_off);
-        XV_HIP(h, launch_att_softmax(sc, d.att_num_heads, off, B, 14, s));
-        if (st.to_out) XV_HIP(h, launch_att_weights_out(sc, d.att_num_heads, off, B, 14, out, s));
+        XV_HIP(h, launch_att_softmax(sc, d.att_num_heads, off, B, h->final_ctx, s));
+        if (st.to_out) XV_HIP(h, launch_att_weights_out(sc, d.att_num_heads, off, B, h->final_ctx, out, s));
         break;
       }
       case OP_ATT_POOL: {

@@ -37,20 +37,35 @@ def _prelu(rs, w, scope, n, params):
         w[scope + "/alpha"] = (0.01 + 0.2 * rs.uniform(0, 1, n)).astype(np.float32)
 
 
+_NETS = {"tdnn": ("tdnn", (5, 5, 7, 1, 1), 4, (6, 7)),                                  # model/tdnn.py:36-181
+         "extended_tdnn": ("etdnn", (5, 1, 5, 1, 7, 1, 9, 1, 1, 1), 3, (12, 13))}       # model/tdnn.py:343-591
+
+
+def net_spec(params):
+    """(variable scope, frame-layer kernel widths, conv kernel rank, segment layer indices)."""
+    return _NETS[_get(params, "network_type", "tdnn")]
+
+
 def tdnn_layer_dims(params, dim, channels=512):
-    """(name, kernel_width, cin, cout) of the seven affine layers of model/tdnn.py."""
+    """(name, kernel_width, cin, cout) of the affine layers of model/tdnn.py tdnn() / etdnn()."""
+    _, widths, _, seg = net_spec(params)
     pool_nodes = int(_get(params, "num_nodes_pooling_layer", 1500))
     last_nodes = int(_get(params, "num_nodes_last_layer", 512))
     pool_dim = pooling_output_dim(params, pool_nodes, channels)
-    return [("tdnn1_conv", 5, dim, channels), ("tdnn2_conv", 5, channels, channels),
-            ("tdnn3_conv", 7, channels, channels), ("tdnn4_dense", 1, channels, channels),
-            ("tdnn5_dense", 1, channels, pool_nodes), ("tdnn6_dense", 1, pool_dim, channels),
-            ("tdnn7_dense", 1, channels, last_nodes)]
+    out, cin = [], dim
+    for i, w in enumerate(widths, start=1):
+        cout = pool_nodes if i == len(widths) else channels
+        out.append(("tdnn%d_%s" % (i, "conv" if w > 1 else "dense"), w, cin, cout))
+        cin = cout
+    out.append(("tdnn%d_dense" % seg[0], 1, pool_dim, channels))
+    out.append(("tdnn%d_dense" % seg[1], 1, channels, last_nodes))
+    return out
 
 
 def _node_width(params, node, channels, pool_nodes):
     """Channel count of a frame-level endpoint used as attention key/value input."""
-    if node.startswith("tdnn5"):
+    nframe = len(net_spec(params)[1])
+    if node.startswith("tdnn%d_" % nframe):
         return pool_nodes
     return channels
 
@@ -70,20 +85,22 @@ def synth_weights(params, dim, seed=0, channels=512):
     rs = np.random.RandomState(seed)
     w = OrderedDict()
     pool_nodes = int(_get(params, "num_nodes_pooling_layer", 1500))
+    scope, _, rank, seg = net_spec(params)
     for name, k, cin, cout in tdnn_layer_dims(params, dim, channels):
-        idx = name[4]
-        scope = "tdnn/" + name
+        idx = name[4:name.index("_")]
+        vs = scope + "/" + name
         if name.endswith("conv"):
-            w[scope + "/kernel"] = _glorot(rs, (1, k, cin, cout))
+            w[vs + "/kernel"] = _glorot(rs, (1, k, cin, cout) if rank == 4 else (k, cin, cout))
         else:
-            w[scope + "/kernel"] = _glorot(rs, (cin, cout))
-        w[scope + "/bias"] = (0.1 * rs.standard_normal(cout)).astype(np.float32)
-        if not (idx == "7" and _get(params, "last_layer_no_bn", False)):
-            _bn(rs, w, "tdnn/tdnn%s_bn" % idx, cout)
-        if not (idx == "7" and _get(params, "last_layer_linear", False)):
-            _prelu(rs, w, "tdnn/tdnn%s_relu" % idx, cout, params)
+            w[vs + "/kernel"] = _glorot(rs, (cin, cout))
+        w[vs + "/bias"] = (0.1 * rs.standard_normal(cout)).astype(np.float32)
+        last = idx == str(seg[1])
+        if not (last and _get(params, "last_layer_no_bn", False)):
+            _bn(rs, w, "%s/tdnn%s_bn" % (scope, idx), cout)
+        if not (last and _get(params, "last_layer_linear", False)):
+            _prelu(rs, w, "%s/tdnn%s_relu" % (scope, idx), cout, params)
     if _get(params, "pooling_type") == "self_attention":
-        base = "tdnn/attention"
+        base = scope + "/attention"
         for which in ("key", "value"):
             nodes = list(_get(params, "att_%s_num_nodes" % which))
             cin = _node_width(params, _get(params, "att_%s_input" % which), channels, pool_nodes)

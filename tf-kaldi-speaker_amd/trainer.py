@@ -26,12 +26,17 @@ def _relu_type(params):
     return {"prelu": _lib.XV_ACT_PRELU, "lrelu": _lib.XV_ACT_LRELU}.get(t, _lib.XV_ACT_RELU)
 
 
+_NETWORK_TYPES = {"tdnn": 0, "extended_tdnn": 1}          # XV_NET_* (model/trainer.py:100-110)
+
+
 def _endpoint_index(name, what):
-    """'tdnn4_relu' -> 4 (attention key/value inputs must be frame-level relu endpoints)."""
-    for i in (3, 4, 5):
-        if name == "tdnn%d_relu" % i:
-            return i
-    raise NotImplementedError("%s=%r: only tdnn3_relu/tdnn4_relu/tdnn5_relu are supported" % (what, name))
+    """'tdnn4_relu' -> 4.  Attention key/value inputs must be the relu endpoint of a frame-level
+    layer at full temporal context (the library checks the index against the graph)."""
+    import re
+    m = re.match(r"^tdnn(\d+)_relu$", name)
+    if not m:
+        raise NotImplementedError("%s=%r: only tdnn<N>_relu endpoints are supported" % (what, name))
+    return int(m.group(1))
 
 
 class Trainer(object):
@@ -41,9 +46,9 @@ class Trainer(object):
                  device=None, precision=None):
         # model/trainer.py:100-110 network dispatch.  Only the TDNN is on this round's hot path.
         self.network_type = params.network_type
-        if params.network_type != "tdnn":
-            if params.network_type in ("tdnn-s", "extended_tdnn", "resnet_18"):
-                raise NotImplementedError("%s network is not built yet (SURVEY.md 8f)" % params.network_type)
+        if params.network_type not in _NETWORK_TYPES:
+            if params.network_type in ("tdnn-s", "resnet_18"):
+                raise NotImplementedError("%s network is not built yet (SURVEY.md 8a16 / 8f)" % params.network_type)
             raise NotImplementedError("Not implement %s network" % params.network_type)
         self.params = params
         self.model = os.path.join(model_dir, "nnet") if model_dir is not None else None
@@ -98,7 +103,7 @@ class Trainer(object):
         p = self.params
         d = _lib.ModelDesc()
         d.struct_size = C.sizeof(_lib.ModelDesc)
-        d.network_type = 0
+        d.network_type = _NETWORK_TYPES[p.network_type]
         d.feat_dim = self.dim
         d.channels = int(channels)
         d.pooling_type = _lib.XV_POOL_SELF_ATTENTION if p.pooling_type == "self_attention" else _lib.XV_POOL_STATISTICS
@@ -155,7 +160,8 @@ class Trainer(object):
         self._torch = torch
         self._lib = _lib.load()
         self._release()
-        k1 = np.asarray(weights["tdnn/tdnn1_conv/kernel"])
+        scope = "etdnn" if self.params.network_type == "extended_tdnn" else "tdnn"
+        k1 = np.asarray(weights[scope + "/tdnn1_conv/kernel"])
         desc = self._make_desc(channels=k1.shape[-1])
         h = C.c_void_p()
         _lib.check(self._lib.xv_create(C.byref(desc), self._device_index, C.byref(h)))
