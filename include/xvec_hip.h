@@ -51,7 +51,7 @@ typedef enum {
 
 /* network_type: model/trainer.py:100-110.  "tdnn" = model/tdnn.py:10-181, "extended_tdnn" = the
  * 10-frame-layer variant model/tdnn.py:343-591 (variable scope "etdnn", conv1d kernels [w,cin,cout]) */
-enum { XV_NET_TDNN = 0, XV_NET_ETDNN = 1 };
+enum { XV_NET_TDNN = 0, XV_NET_ETDNN = 1, XV_NET_RESNET18 = 2 };   /* resnet_18: model/resnet.py:152-351 */
 /* pooling_type: model/pooling.py:14-23 */
 enum { XV_POOL_STATISTICS = 0, XV_POOL_SELF_ATTENTION = 1 };
 /* network_relu_type: model/tdnn.py:28-33 */
@@ -96,6 +96,8 @@ typedef struct {
   int32_t att_split_value;
   int32_t att_split_key;
   int32_t precision;                /* XV_PREC_*                                           */
+  int32_t resnet_blocks[4];         /* resnet_18: blocks per stage, default [2,2,2,2] (model/resnet.py:203-204);
+                                       `channels` is then the width of stage 1 (64)            */
 } xv_model_desc;
 
 typedef struct {

@@ -198,3 +198,110 @@ class TorchTdnn(object):
         ep = self.forward(features)
         e = ep[node if node else _get(self.params, "embedding_node")].numpy()
         return e[0] if rank == 2 else e
+
+
+class TorchResnet18(object):
+    """fp32 torch restatement of model/resnet.py:152-351 with F.conv2d on NCHW tensors and
+    explicit F.pad for TensorFlow's asymmetric 'same' padding (independent of the tap-loop
+    formulation in oracle/ref_numpy.py)."""
+
+    def __init__(self, weights, params, dtype=torch.float32):
+        self.params = params
+        self.dtype = dtype
+        self.w = {k: torch.from_numpy(np.ascontiguousarray(np.asarray(v))).to(dtype) for k, v in weights.items()}
+        self.scope = "resnet_18"
+
+    def _bn(self, x, name):                                # x NCHW or [b,l,c]
+        w, s = self.w, self.scope + "/" + name
+        sc = w[s + "/gamma"] / torch.sqrt(w[s + "/moving_variance"] + BN_EPSILON)
+        sh = w[s + "/beta"] - w[s + "/moving_mean"] * sc
+        if x.dim() == 4:
+            return x * sc[None, :, None, None] + sh[None, :, None, None]
+        return x * sc + sh
+
+    def _act(self, x, name):
+        t = _get(self.params, "network_relu_type")
+        if t == "prelu":
+            a = self.w[self.scope + "/" + name + "/alpha"]
+            if x.dim() == 4:
+                a = a[None, :, None, None]
+            return F.relu(x) + a * (x - x.abs()) * 0.5
+        if t == "lrelu":
+            return F.leaky_relu(x, LRELU_ALPHA)
+        return F.relu(x)
+
+    def _conv_same(self, x, name, strides=(1, 1)):
+        k = self.w[self.scope + "/" + name + "/kernel"]    # HWIO
+        kh, kw = k.shape[0], k.shape[1]
+        pads = []
+        for n, kk, st in ((x.shape[3], kw, strides[1]), (x.shape[2], kh, strides[0])):   # F.pad: last dim first
+            out = -(-n // st)
+            tot = max((out - 1) * st + kk - n, 0)
+            pads += [tot // 2, tot - tot // 2]
+        return F.conv2d(F.pad(x, pads), k.permute(3, 2, 0, 1).contiguous(), stride=strides)
+
+    def _block(self, x, name, strides, projection, ep):
+        f = self._act(self._bn(self._conv_same(x, name + "_conv0", strides), name + "_bn0"), name + "_relu0")
+        f = self._bn(self._conv_same(f, name + "_conv1"), name + "_bn1")
+        sc = self._bn(self._conv_same(x, name + "_conv_short", strides), name + "_bn_short") if projection else x
+        f = self._act(f + sc, name + "_relu_final")
+        ep[name] = f.permute(0, 2, 3, 1)
+        return f
+
+    @torch.no_grad()
+    def forward(self, features):
+        p, sc = self.params, self.scope
+        if _get(p, "resnet_time_stride", False) or _get(p, "resnet_maxpooling", False):
+            raise NotImplementedError("resnet_time_stride / resnet_maxpooling")
+        blocks = list(_get(p, "resnet_blocks", [2, 2, 2, 2]))
+        ep = OrderedDict()
+        x = torch.as_tensor(np.ascontiguousarray(features)).to(self.dtype)[:, None]       # [b,1,l,40]
+        x = self._act(self._bn(self._conv_same(x, "conv0_1"), "conv0_bn"), "conv0_relu")
+        ep["conv0_relu"] = x.permute(0, 2, 3, 1)
+        for stage in (1, 2, 3, 4):
+            x = self._block(x, "conv%da" % stage, (1, 1) if stage == 1 else (1, 2), True, ep)
+            for i in range(blocks[stage - 1] - 1):
+                x = self._block(x, "conv%db_%d" % (stage, i), (1, 1), False, ep)
+        k5 = self.w[sc + "/conv5/kernel"].permute(3, 2, 0, 1).contiguous()
+        x = F.conv2d(x, k5, self.w[sc + "/conv5/bias"])
+        x = self._act(self._bn(x, "conv5_bn"), "conv5_relu")[:, :, :, 0].transpose(1, 2)   # [b,l,512]
+        ep["conv5_relu"] = x
+        for name in ("dense1", "dense2"):
+            x = F.linear(x, self.w["%s/%s/kernel" % (sc, name)].t(), self.w["%s/%s/bias" % (sc, name)])
+            x = self._act(self._bn(x, name + "_bn"), name + "_relu")
+            ep[name + "_relu"] = x
+        if _get(p, "pooling_type") != "statistics_pooling":
+            raise NotImplementedError("resnet_18 registers no frame-level endpoints for attention inputs")
+        mean = x.mean(dim=1, keepdim=True)
+        var = ((x - mean) ** 2).mean(dim=1)
+        var = torch.where(var <= VAR2STD_EPSILON, torch.full_like(var, VAR2STD_EPSILON), var)
+        x = torch.cat([mean[:, 0], var.sqrt()], dim=1)
+        ep["pooling"] = x
+        x = F.linear(x, self.w[sc + "/tdnn6_dense/kernel"].t(), self.w[sc + "/tdnn6_dense/bias"])
+        ep["tdnn6_dense"] = x
+        x = self._bn(x, "tdnn6_bn")
+        ep["tdnn6_bn"] = x
+        x = self._act(x, "tdnn6_relu")
+        ep["tdnn6_relu"] = x
+        x = F.linear(x, self.w[sc + "/tdnn7_dense/kernel"].t(), self.w[sc + "/tdnn7_dense/bias"])
+        ep["tdnn7_dense"] = x
+        if not _get(p, "last_layer_no_bn", False):
+            x = self._bn(x, "tdnn7_bn")
+            ep["tdnn7_bn"] = x
+        if not _get(p, "last_layer_linear", False):
+            x = self._act(x, "tdnn7_relu")
+            ep["tdnn7_relu"] = x
+        ep["output"] = x
+        if _get(p, "feature_norm", False):
+            sq = (x * x).sum(-1, keepdim=True)
+            ep["output"] = x * (float(_get(p, "feature_scaling_factor")) * torch.rsqrt(torch.clamp(sq, min=1e-12)))
+        return ep
+
+    def predict(self, features, dim=40, node=None):
+        features = np.asarray(features)
+        rank = features.ndim
+        if rank == 2:
+            features = features[None]
+        ep = self.forward(features[:, :, :dim])
+        e = ep[node if node else _get(self.params, "embedding_node")].numpy()
+        return e[0] if rank == 2 else e

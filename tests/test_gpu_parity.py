@@ -153,6 +153,46 @@ def test_extended_tdnn_every_endpoint(precision, pooling):
     tr.close()
 
 
+@pytest.mark.parametrize("width,precision", [(8, "f32"), (32, "f32"), (32, "bf16x3")])
+def test_resnet18_every_block(width, precision):
+    """network_type "resnet_18" (model/resnet.py:152-351) block by block on a ragged batch; width 8 runs the
+    fp32 kernels with 24-wide taps, width 32 the split kernel on whole SB blocks."""
+    import torch
+    from tf_kaldi_speaker_amd import synth
+    params = dict(synth.RESNET_PARAMS, num_nodes_pooling_layer=96, network_relu_type="prelu", resnet_blocks=[2, 1, 2, 2])
+    weights = synth.synth_resnet_weights(params, seed=5, width=width)
+    lens = [9, 14, 3]
+    utts = synth.synth_features(len(lens), lens, 40, seed=15)
+    tr, _ = _trainer(params, weights, 40, precision)
+    packed = torch.from_numpy(np.concatenate(utts, axis=0)).cuda()
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    eps = [ref_numpy.entire_network(u[None], weights, params)[1] for u in utts]
+    for name in eps[0]:
+        got = tr.predict_packed(packed, offsets, node=name).cpu().numpy()
+        ref = np.concatenate([e[name].reshape(-1, e[name].shape[-1]) for e in eps], axis=0)
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        err = _rel(got, ref)
+        _note("resnet_w%d" % width, precision, name, err)
+        assert err <= TOL, (name, err)
+    tr.close()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_resnet18_full_width_xvector(precision):
+    """config 5 graph at full width (64..512 channels, 13.5 M parameters), short utterances."""
+    from tf_kaldi_speaker_amd import synth
+    params = dict(synth.RESNET_PARAMS)
+    weights = synth.synth_resnet_weights(params, seed=0)
+    feats = np.stack(synth.synth_features(2, 24, 40, seed=16))
+    ref = ref_numpy.predict(feats, weights, params, 40)
+    tr, _ = _trainer(params, weights, 40, precision)
+    got = tr.predict(feats)
+    err = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    _note("resnet_full", precision, "tdnn6_dense", err.max())
+    assert err.max() <= TOL, err
+    tr.close()
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_xvector_300_frames(stat_model, precision):
     """BASELINE config 2 shape (30-dim x 300 frames), small batch, tdnn6_dense."""

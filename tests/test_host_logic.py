@@ -116,13 +116,16 @@ def test_c_abi_library_exports_every_declared_symbol(repo_root):
         assert hasattr(lib, name), name
     lib.xv_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.xv_version()
-    assert ctypes.sizeof(_lib.ModelDesc) == 4 * (26 + 2 * (_lib.XV_MAX_ATT_LAYERS - 1))
+    assert ctypes.sizeof(_lib.ModelDesc) == 4 * (30 + 2 * (_lib.XV_MAX_ATT_LAYERS - 1))
 
 
 def test_trainer_refuses_unsupported_graphs_and_missing_gpu():
     from tf_kaldi_speaker_amd.trainer import Trainer
     with pytest.raises(NotImplementedError):
-        Trainer(Params(**dict(synth.TDNN_STAT_PARAMS, network_type="resnet_18")), None, 40)
+        Trainer(Params(**dict(synth.TDNN_STAT_PARAMS, network_type="tdnn-s")), None, 30)
+    rn = Trainer(Params(**dict(synth.RESNET_PARAMS, resnet_time_stride=True)), None, 40)
+    with pytest.raises(NotImplementedError):
+        rn.build("predict")
     with pytest.raises(NotImplementedError):
         Trainer(Params(**dict(synth.TDNN_STAT_PARAMS, network_type="nonsense")), None, 30)
     tr = Trainer(Params(**dict(synth.TDNN_STAT_PARAMS, pooling_type="ghost_vlad")), None, 30)

@@ -91,6 +91,45 @@ def test_extended_tdnn_restatements_agree(pooling):
         assert np.linalg.norm(a - b) / max(np.linalg.norm(a), 1e-30) < 2e-6, k
 
 
+@pytest.mark.parametrize("kw", [{}, {"network_relu_type": "prelu", "resnet_blocks": [1, 2, 1, 3]},
+                                {"network_relu_type": "lrelu", "last_layer_linear": True}])
+def test_resnet18_restatements_agree(kw):
+    """model/resnet.py:152-351: numpy tap-loop conv vs torch F.conv2d with explicit TF 'same' padding
+    (stride-2 frequency axis pads 0 before / 1 after)."""
+    p = dict(synth.RESNET_PARAMS, num_nodes_pooling_layer=48, **kw)
+    w = synth.synth_resnet_weights(p, seed=1, width=8)
+    feats = np.stack(synth.synth_features(2, 13, 40, seed=3))
+    _, ep = ref_numpy.entire_network(feats, w, p)
+    ep_t = ref_torch.TorchResnet18(w, p).forward(feats)
+    assert ep["conv2a"].shape == (2, 13, 20, 16) and ep["conv4a"].shape == (2, 13, 5, 64)      # 40 -> 20 -> 10 -> 5
+    assert ep["conv5_relu"].shape == (2, 13, 64) and ep["tdnn6_dense"].shape == (2, 64)
+    for k in ep:
+        a, b = ep[k], ep_t[k].numpy().astype(np.float64)
+        assert a.shape == b.shape, k
+        assert np.linalg.norm(a - b) / max(np.linalg.norm(a), 1e-30) < 2e-6, k
+
+
+def test_resnet18_parameter_count_matches_reference_formula():
+    """model/resnet.py:292-297 `num_params` (frame-level network, BN excluded) for blocks [2,2,2,2]: 13.5 M (:170)."""
+    w = synth.synth_resnet_weights(dict(synth.RESNET_PARAMS), seed=0)
+    got = sum(v.size for k, v in w.items() if k.endswith("/kernel") and "tdnn" not in k)
+    blocks = [2, 2, 2, 2]
+    ref = 3*3*64 + (2*3*3*64*64*blocks[0] + 64*64) + \
+        (3*3*64*128 + 3*3*128*128 + 64*128 + 2*3*3*128*128*(blocks[1]-1)) + \
+        (3*3*128*256 + 3*3*256*256 + 128*256 + 2*3*3*256*256*(blocks[2]-1)) + \
+        (3*3*256*512 + 3*3*512*512 + 256*512 + 2*3*3*512*512*(blocks[3]-1)) + \
+        (1*5*512*512 + 512*512 + 512*1500)
+    assert got == ref == 13503040
+
+
+def test_tf_same_padding_stride2_is_asymmetric():
+    """k=3, s=2, n even: pad 0 before / 1 after (TF 'same'), unlike a symmetric pad of 1."""
+    x = np.arange(1 * 1 * 6 * 1, dtype=np.float64).reshape(1, 1, 6, 1)
+    k = np.ones((1, 3, 1, 1))
+    y = ref_numpy.conv2d(x, k, strides=(1, 2))
+    assert y[0, 0, :, 0].tolist() == [0 + 1 + 2, 2 + 3 + 4, 4 + 5]
+
+
 def test_full_size_tdnn_restatements_agree():
     p = dict(synth.TDNN_STAT_PARAMS)
     w = synth.synth_weights(p, 30, seed=0)

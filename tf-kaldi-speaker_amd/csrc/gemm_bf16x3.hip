@@ -162,14 +162,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
   const int gps = (ngroups + w - 1) / w;            // groups issued per step
   // per-lane DMA source: row (lane >> 3) of the group, swizzled chunk
   const int lrow = lane >> 3, lpc = lane & 7;
-  const int64_t a_row_bytes = p.ldsbx * 4, b_row_bytes = (int64_t)p.Kpad * 4;
-  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + (int64_t)(m0 + lrow) * a_row_bytes;
+  // A addressing: default 1-D form (row pitch = ldsbx) or the grid form of GemmArgs (pitch / offset /
+  // taps with a stride; then w == 1 and K step s is (tap, block) = (s / kbt, s % kbt))
+  const int64_t a_row_bytes = (p.a_pitch ? p.a_pitch : p.ldsbx) * 4, b_row_bytes = (int64_t)p.Kpad * 4;
+  const int kbt = p.a_pitch ? (p.ktap >> 5) : (p.Kpad >> 5);       // K blocks per tap
+  const int64_t tap_bytes = p.a_pitch ? p.tap_stride * 4 : 0;
+  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(m0 + lrow) * a_row_bytes;
   const char* Bg = reinterpret_cast<const char*>(p.Wsb) + (int64_t)(n0 + lrow) * b_row_bytes;
 
   // group g covers rows 8g .. 8g+7; this lane's row is 8g + lrow and (row >> 1) & 7 == (4g + (lrow >> 1)) & 7
-  auto dma_a = [&](int cb, int buf, int g) {
+  // `koff` = byte offset of the K block inside a row: cb*128 in the 1-D form, tap*tap_bytes + blk*128
+  // in the grid form (kept incrementally by the caller: no division in the loop)
+  auto dma_a = [&](int64_t koff, int buf, int g) {
     const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
-    __builtin_amdgcn_global_load_lds((gptr_t)(Ag + (int64_t)(8 * g) * a_row_bytes + cb * 128 + c * 16),
+    __builtin_amdgcn_global_load_lds((gptr_t)(Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16),
                                      (lptr_t)(As + buf * DA_BYTES + g * 1024), 16, 0, 0);
   };
   auto dma_b = [&](int kb, int buf, int g) {
@@ -188,6 +194,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
 
   // prologue: whole slab 0 and the weight tile of step 0
   for (int g = wave; g < ngroups; g += 4) dma_a(0, 0, g);
+  int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : 128;   // K-block offset of slab cb + 1
+  int blk_next = (kbt == 1 && p.a_pitch) ? 0 : 1;                  // its block index inside the tap
 #pragma unroll
   for (int q = 0; q < 4; ++q) dma_b(0, 0, wave + 4 * q);
   __syncthreads();
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
     }
     if (cb + 1 < ncb && !(diag & 8)) {     // diag bit3: no slab DMA in the loop (timing only)
       const int gend = min((j + 1) * gps, ngroups);
-      for (int g = j * gps + wave; g < gend; g += 4) dma_a((diag & 32) ? 0 : cb + 1, (cb + 1) & 1, g);
+      for (int g = j * gps + wave; g < gend; g += 4) dma_a((diag & 32) ? 0 : koff_next, (cb + 1) & 1, g);
     }
 
     const char* ab = As + (cb & 1) * DA_BYTES;
@@ -259,6 +267,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
       __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     }
     if (!(diag & 16)) __syncthreads();     // diag bit4: no barrier (timing only, racy)
+    if (cb_next != cb) {                 // advance the A K-block offset with the slab index
+      if (++blk_next == kbt) {
+        blk_next = 0;
+        koff_next += tap_bytes - (int64_t)(kbt - 1) * 128;
+      } else {
+        koff_next += 128;
+      }
+    }
     cb = cb_next;
     j = j_next;
   }

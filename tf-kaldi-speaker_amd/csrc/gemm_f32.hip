@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, i
     p.rowmap = nullptr;
     p.raw = 1;
     p.act = ACT_NONE;
+    p.R = nullptr;                       // the shortcut is added once, by splitk_reduce_kernel
   }
 
   f32x4 ra[4], rb[4];
@@ -68,10 +69,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, i
       const int row = lr + 32 * i;
       rb[i] = *reinterpret_cast<const f32x4*>(p.Wt + (int64_t)(n0 + row) * p.Kpad + k);
       if (ALIGNED) {
-        if (k < p.K)
-          ra[i] = *reinterpret_cast<const f32x4*>(p.X + (int64_t)(m0 + row) * p.ldx + k);
-        else
+        if (k >= p.K) {
           ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if (p.a_pitch) {        // grid form: A[m, tap*ktap + kk] = X[a_off + m*a_pitch + tap*tap_stride + kk]
+          const int tap = k / p.ktap;
+          ra[i] = *reinterpret_cast<const f32x4*>(p.X + p.a_off + (int64_t)(m0 + row) * p.a_pitch +
+                                                  (int64_t)tap * p.tap_stride + (k - tap * p.ktap));
+        } else {
+          ra[i] = *reinterpret_cast<const f32x4*>(p.X + (int64_t)(m0 + row) * p.ldx + k);
+        }
       } else {
         const int m = m0 + row;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -148,9 +154,11 @@ __global__ void splitk_reduce_kernel(GemmArgs p) {
     const int m = (int)(i / p.N), n = (int)(i - (int64_t)m * p.N);
     float acc = 0.f;
     for (int s = 0; s < p.ksplit; ++s) acc += p.partial[((int64_t)s * p.M + m) * p.Npad + n];
-    const float v = apply_act(fmaf(acc, p.scale[n], p.shift[n]), p.act, p.alpha ? p.alpha[n] : 0.f);
     const int orow = p.rowmap ? p.rowmap[m] : m;
-    if (orow >= 0) p.Y[(int64_t)orow * p.ldy + n] = v;
+    if (orow < 0) continue;
+    float v = fmaf(acc, p.scale[n], p.shift[n]);
+    if (p.R) v += p.R[(int64_t)orow * p.ldr + n];          // residual shortcut before the activation
+    p.Y[(int64_t)orow * p.ldy + n] = apply_act(v, p.act, p.alpha ? p.alpha[n] : 0.f);
   }
 }
 

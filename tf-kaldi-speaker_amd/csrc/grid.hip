@@ -1,0 +1,160 @@
+// Index and layout helpers for the ResNet-18 encoder (model/resnet.py:152-351).
+//
+// 2-D activations live on a zero-bordered NHWC "grid": utterance b owns (L_b + 2) x (F + 2) positions
+// of C channels starting at position (off0[b] + 2b) * (F + 2); the border stays zero, so TensorFlow's
+// 'same' padding of the 3x3 convolutions needs no bounds checks and every kernel row of a window is
+// one contiguous run of 3*C values -- the convolution becomes the overlapping-row GEMM of
+// xv_kernels.h (taps = kernel rows, tap stride = one padded time row).
+#include "xv_epilogue.h"
+
+namespace xv {
+
+namespace {
+
+// utterance whose block [start_b, start_{b+1}) contains r, with start_b = (off0[b] + 2b) * unit
+__device__ __forceinline__ int find_utt(const int32_t* off0, int B, int64_t unit, int64_t r) {
+  int lo = 0, hi = B - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int64_t)(off0[mid] + 2 * mid) * unit <= r) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ void rowmap_grid_kernel(const int32_t* __restrict__ off0, int B, int rows_per_t, int Fout,
+                                   int32_t* __restrict__ rowmap, int64_t M) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int b = find_utt(off0, B, rows_per_t, m);
+  const int64_t local = m - (int64_t)(off0[b] + 2 * b) * rows_per_t;
+  const int t = (int)(local / rows_per_t), j = (int)(local - (int64_t)t * rows_per_t);
+  const int L = off0[b + 1] - off0[b];
+  const int So = Fout + 2;
+  rowmap[m] = (t < L && j < Fout) ? (int32_t)((int64_t)(off0[b] + 2 * b) * So + (int64_t)(t + 1) * So + j + 1) : -1;
+}
+
+__global__ void rowmap_rows_kernel(const int32_t* __restrict__ off0, int B, int32_t* __restrict__ rowmap, int64_t M) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int b = find_utt(off0, B, 1, m);
+  const int t = (int)(m - (off0[b] + 2 * b));
+  const int L = off0[b + 1] - off0[b];
+  rowmap[m] = (t >= 1 && t <= L) ? off0[b] + t - 1 : -1;
+}
+
+__global__ void rowmap_interior_kernel(const int32_t* __restrict__ off0, int B, int F, int32_t* __restrict__ rowmap,
+                                       int64_t M) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const int S = F + 2;
+  const int b = find_utt(off0, B, S, p);
+  const int64_t local = p - (int64_t)(off0[b] + 2 * b) * S;
+  const int t = (int)(local / S), f = (int)(local - (int64_t)t * S);
+  const int L = off0[b + 1] - off0[b];
+  rowmap[p] = (t >= 1 && t <= L && f >= 1 && f <= F) ? (int32_t)p : -1;
+}
+
+// conv0 (3x3, cin = 1): one thread per (output grid position, pair of taps); taps 9..31 are zero padding
+template <bool SB>
+__global__ void im2col2d_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ off0, int B, int F,
+                                int64_t P, char* __restrict__ out) {
+  const int64_t total = P * 16;
+  const int S = F + 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i >> 4;
+    const int k = (int)(i & 15) * 2;
+    const int b = find_utt(off0, B, S, p);
+    const int64_t local = p - (int64_t)(off0[b] + 2 * b) * S;
+    const int tp = (int)(local / S), fp = (int)(local - (int64_t)tp * S);
+    const int L = off0[b + 1] - off0[b];
+    float v[2] = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int kk = k + e;
+      if (kk < 9) {
+        const int t = tp + kk / 3 - 2, f = fp + kk % 3 - 2;       // output (tp-1, fp-1), tap (kh-1, kw-1)
+        if (t >= 0 && t < L && f >= 0 && f < F) v[e] = x[(int64_t)(off0[b] + t) * ldx + f];
+      }
+    }
+    if (SB) {
+      uint32_t hi, lo;
+      split2(v[0], v[1], hi, lo);
+      char* blk = out + p * 128 + k * 2;
+      *reinterpret_cast<uint32_t*>(blk) = hi;
+      *reinterpret_cast<uint32_t*>(blk + 64) = lo;
+    } else {
+      float* row = reinterpret_cast<float*>(out) + p * 32 + k;
+      row[0] = v[0];
+      row[1] = v[1];
+    }
+  }
+}
+
+__global__ void grid_unpad_kernel(const float* __restrict__ grid, const int32_t* __restrict__ off0, int B, int F, int C,
+                                  float* __restrict__ out, int64_t total) {
+  const int S = F + 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t pos = i / C;                 // dense position: frame * F + f
+    const int f = (int)(pos % F);
+    const int64_t frame = pos / F;
+    int lo = 0, hi = B - 1;                    // utterance of this frame
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (off0[mid] <= frame) lo = mid; else hi = mid - 1;
+    }
+    const int t = (int)(frame - off0[lo]);
+    const int64_t p = (int64_t)(off0[lo] + 2 * lo) * S + (int64_t)(t + 1) * S + f + 1;
+    out[i] = grid[p * C + c];
+  }
+}
+
+int launch_blocks(int64_t total) { return (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256); }
+
+}  // namespace
+
+hipError_t launch_build_rowmap_grid(const int32_t* off0, int B, int rows_per_t, int Fout, int32_t* rowmap, int64_t M,
+                                    hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rowmap_grid_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, off0, B, rows_per_t, Fout,
+                     rowmap, M);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_rowmap_rows(const int32_t* off0, int B, int32_t* rowmap, int64_t M, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rowmap_rows_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, off0, B, rowmap, M);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_rowmap_interior(const int32_t* off0, int B, int F, int32_t* rowmap, int64_t M, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rowmap_interior_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, off0, B, F, rowmap, M);
+  return hipGetLastError();
+}
+
+hipError_t launch_im2col2d_sb(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int64_t P, void* out_sb,
+                              hipStream_t s) {
+  if (P <= 0) return hipSuccess;
+  hipLaunchKernelGGL(im2col2d_kernel<true>, dim3(launch_blocks(P * 16)), dim3(256), 0, s, x, ldx, off0, B, F, P,
+                     static_cast<char*>(out_sb));
+  return hipGetLastError();
+}
+
+hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int64_t P, float* out,
+                               hipStream_t s) {
+  if (P <= 0) return hipSuccess;
+  hipLaunchKernelGGL(im2col2d_kernel<false>, dim3(launch_blocks(P * 16)), dim3(256), 0, s, x, ldx, off0, B, F, P,
+                     reinterpret_cast<char*>(out));
+  return hipGetLastError();
+}
+
+hipError_t launch_grid_unpad_n(const float* grid, const int32_t* off0, int B, int F, int C, int64_t frames, float* out,
+                               hipStream_t s) {
+  const int64_t total = frames * F * C;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(grid_unpad_kernel, dim3(launch_blocks(total)), dim3(256), 0, s, grid, off0, B, F, C, out, total);
+  return hipGetLastError();
+}
+
+}  // namespace xv

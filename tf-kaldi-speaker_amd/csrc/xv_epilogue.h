@@ -63,7 +63,12 @@ __device__ __forceinline__ void store_tile_scalar(const GemmArgs& p, const f32x1
   for (int e = 0; e < 16; ++e) {
     const int n = nbase + (e & 3) + 8 * (e >> 2) + 4 * h;
     const bool nok = n < p.N;
-    const float v = nok ? apply_act(fmaf(acc[e], p.scale[n], p.shift[n]), p.act, p.alpha ? p.alpha[n] : 0.f) : 0.f;
+    float v = 0.f;
+    if (nok) {
+      v = p.raw ? acc[e] : fmaf(acc[e], p.scale[n], p.shift[n]);
+      if (p.R) v += p.R[(int64_t)orow * p.ldr + n];
+      v = apply_act(v, p.raw ? ACT_NONE : p.act, p.alpha ? p.alpha[n] : 0.f);
+    }
     if (p.Y && nok) p.Y[(int64_t)orow * p.ldy + n] = v;
     if (p.Ysb && n < p.ldsb) {
       uint32_t hi, lo;
@@ -109,6 +114,56 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
     al = (ok && p.alpha) ? *reinterpret_cast<const f32x4*>(p.alpha + n4) : z;
   };
 
+  if (p.R) {
+    // residual form (model/resnet.py:84-85,147-148): y = act(bn(conv) + shortcut).  Stage the BN output in
+    // LDS, then add the fp32 shortcut row-wise (coalesced 16-byte loads), activate, and store fp32 / SB.
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 sc, sh, al;
+        params(nbase + ni * 32 + 8 * q + 4 * h, sc, sh, al);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row = mi * 32 + r32;
+          f32x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fmaf(acc[ni][mi][4 * q + i], sc[i], sh[i]);
+          *reinterpret_cast<f32x4*>(scratch + row * 256 + (((ni * 8 + 2 * q + h) ^ (row & 15)) << 4)) = v;
+        }
+      }
+    __syncthreads();
+    const int n = nbase + rchunk * 4;
+    const bool nok = n < p.N;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 al4 = (nok && p.alpha) ? *reinterpret_cast<const f32x4*>(p.alpha + n) : z;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + rrow;
+      const int m = mbase + row;
+      f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
+      int orow = -1;
+      if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+      if (orow < 0) continue;
+      if (nok) {
+        v += *reinterpret_cast<const f32x4*>(p.R + (int64_t)orow * p.ldr + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], p.act, al4[i]);
+        if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
+      } else {
+        v = z;
+      }
+      if (p.Ysb && n < p.ldsb) {
+        uint32_t h01, l01, h23, l23;
+        split2(v[0], v[1], h01, l01);
+        split2(v[2], v[3], h23, l23);
+        char* blk = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128 + (n & 31) * 2;
+        *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
+      }
+    }
+    return;
+  }
   if (p.Ysb) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
@@ -230,7 +285,8 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
 // true when the vectorised LDS-staged epilogue applies to this launch
 __device__ __forceinline__ bool wide_epilogue_ok(const GemmArgs& p) {
   return (p.N & 3) == 0 && (!p.Y || ((p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0)) &&
-         (!p.pool_part || p.rowmap == nullptr);
+         (!p.pool_part || p.rowmap == nullptr) &&
+         (!p.R || ((p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.R) & 15) == 0));
 }
 
 // Epilogue entry for a 64x64 wave tile: LDS-staged wide stores when the shape allows, scalar otherwise.

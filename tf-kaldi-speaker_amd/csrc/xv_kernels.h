@@ -54,6 +54,18 @@ struct GemmArgs {
   float* pool_part;
   const int32_t* pool_row2utt;    // [M] utterance index of each row
   const int32_t* pool_slotbase;   // [B]
+  // generalised A addressing (2-D convolutions of the ResNet encoder on a zero-bordered NHWC grid,
+  // model/resnet.py:25-79,217-261).  A[m, tap*ktap + kk] = X[a_off + m*a_pitch + tap*tap_stride + kk]
+  // (element units).  a_pitch == 0 selects the default 1-D form above.  All of a_off, a_pitch,
+  // tap_stride, ktap are multiples of 32 on the bf16x3 path (whole SB blocks).
+  int64_t a_pitch;
+  int64_t a_off;
+  int64_t tap_stride;
+  int ntaps;              // K == ntaps * ktap
+  int ktap;
+  // residual shortcut added before the activation (resnet.py:84-85,147-148): fp32 [rows, N]
+  const float* R;
+  int64_t ldr;
 };
 
 // fp32 MFMA (v_mfma_f32_32x32x2_f32) path.  aligned: ldx == cin (or K == cin), ldx % 4 == 0,
@@ -88,6 +100,25 @@ hipError_t launch_build_row2utt(const int32_t* off0, int B, int ctx, int32_t* ro
 // finalize of the fused statistics pooling: merge the per-segment (sum, M2) pairs of each utterance
 hipError_t launch_pool_finalize(const float* part, int C, const int32_t* off0, int B, int ctx,
                                 const int32_t* slotbase, float* out, int64_t ldo, hipStream_t s);
+
+// ---- ResNet grid helpers.  A "grid" value holds, per utterance b, (L_b + 2) x (F + 2) positions of C
+// channels with a zero border; utterance b starts at position (off0[b] + 2b) * (F + 2).
+// rowmap of a conv whose GEMM rows enumerate (b, t', j): t' in [0, L_b + 2), j in [0, rows_per_t):
+//   valid iff t' < L_b and j < Fout;  out position (off0[b]+2b)*(Fout+2) + (t'+1)*(Fout+2) + j + 1
+hipError_t launch_build_rowmap_grid(const int32_t* off0, int B, int rows_per_t, int Fout, int32_t* rowmap, int64_t M,
+                                    hipStream_t s);
+// rowmap of conv5 (1 x F valid): rows enumerate padded time rows; valid iff 1 <= t' <= L_b -> frame off0[b]+t'-1
+hipError_t launch_build_rowmap_rows(const int32_t* off0, int B, int32_t* rowmap, int64_t M, hipStream_t s);
+// rowmap of conv0 (rows = grid positions): interior -> same position, border -> -1
+hipError_t launch_build_rowmap_interior(const int32_t* off0, int B, int F, int32_t* rowmap, int64_t M, hipStream_t s);
+// conv0 im2col: out SB row p (grid position of the OUTPUT), k = kh*3+kw < 9: x[t+kh-1][f+kw-1] or 0
+hipError_t launch_im2col2d_sb(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int64_t P, void* out_sb,
+                              hipStream_t s);
+hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int64_t P, float* out,
+                               hipStream_t s);
+// grid [P, C] -> dense [sum L_b * F, C] (drops the zero border; test / endpoint output only)
+hipError_t launch_grid_unpad_n(const float* grid, const int32_t* off0, int B, int F, int C, int64_t frames, float* out,
+                               hipStream_t s);
 
 // attention scores (model/pooling.py:189-194): score[r, h] = scale * sum_d key[r, h*dk_h + d] * q[h, d]
 // (split_key) or sum_d key[r, d] * q[h, d] (no split; dk_h == dk).

@@ -21,7 +21,7 @@ using namespace xv;
 namespace {
 
 constexpr double kBnEps = 1e-3;        // tf.layers.batch_normalization default epsilon
-constexpr int kSlackRows = 320;        // readable rows after every activation buffer (GEMM tile overreach)
+constexpr int kSlackRows = 512;        // readable rows after every activation buffer (GEMM tile / conv window overreach)
 constexpr int kAlign = 256;
 
 thread_local std::string g_last_error;  // failures with no handle (xv_create)
@@ -76,6 +76,12 @@ struct Layer {
   DevBuf wsb;                 // split-blocked bf16 hi/lo [Npad][Kpad/32][128 B] (bf16x3 kernel)
   bool use_split = false;     // this layer runs on the bf16x3 kernel
   bool im2col = false;        // first layer in bf16x3 mode: fp32 frames -> SB im2col rows -> dense split GEMM
+  // ResNet 2-D convolutions on the zero-bordered grid (csrc/grid.hip): 0 = 1-D conv / dense,
+  // 1 = 3x3 'same' stride (1,sw), 2 = 1x1 shortcut stride (1,sw), 3 = conv5 (1 x Fin, valid), 4 = conv0 (cin 1)
+  int mode = 0;
+  int Fin = 0, Fout = 0, sw = 1;
+  bool has_bias = true;
+  int K() const { return mode == 1 ? 9 * cin : (mode == 3 ? Fin * cin : (mode == 4 ? 9 : w * cin)); }
   DevBuf vec;                 // [bias | bn_scale | bn_shift | alpha | ones] each cout floats
   int Kpad = 0, Npad = 0;
   int final_stage() const { return act != ACT_NONE ? ST_ACT : (has_bn ? ST_BN : ST_AFFINE); }
@@ -98,6 +104,7 @@ enum OpKind : int {
 
 // A value is a matrix produced by an op (or the network input, value 0).
 struct Value {
+  int grid_F = 0;     // > 0: zero-bordered grid value with grid_F frequency bins (rows = (F0+2B)*(grid_F+2))
   bool frame_level = true;
   int ctx = 0;        // temporal context consumed (frame-level values): rows = F0 - B*ctx
   int cols = 0;
@@ -161,6 +168,7 @@ struct PlanStep {
   int64_t scratch_off = -1;     // per-step scratch (im2col rows / split-K partials), released after the step
   int ksplit = 1;               // split-K slices of a small-M fp32 GEMM
   bool fuse_pool = false;       // GEMM: emit pooling partials instead of activations; STAT_POOL: finalize only
+  bool unpad_to_out = false;    // grid-valued target node: GEMM writes the padded grid, then it is unpadded into `out`
   int64_t flops = 0, bytes = 0;
 };
 
@@ -286,9 +294,112 @@ void add_node(xv_handle* h, const std::string& name, int op, int stage, bool att
   h->nodes.push_back(n);
 }
 
+// one ResNet convolution (+BN, + optional activation / residual); returns the output value id
+int add_conv2d(xv_handle* h, const std::string& var, const std::string& bn, const std::string& relu, int mode, int cin,
+               int cout, int Fin, int Fout, int sw, int act, int in_value, int residual_value, const char* node_name) {
+  Layer L;
+  L.mode = mode; L.cin = cin; L.cout = cout; L.Fin = Fin; L.Fout = Fout; L.sw = sw; L.w = 1;
+  L.kernel_name = var + "/kernel";
+  L.has_bias = (mode == 3);
+  if (mode == 1 || mode == 4) expect(h, L.kernel_name, {3, 3, cin, cout});
+  else if (mode == 2) expect(h, L.kernel_name, {1, 1, cin, cout});
+  else expect(h, L.kernel_name, {1, Fin, cin, cout});
+  if (L.has_bias) { L.bias_name = var + "/bias"; expect(h, L.bias_name, {cout}); }
+  L.has_bn = true;
+  L.bn_scope = bn;
+  expect_bn(h, bn, cout);
+  L.act = act;
+  if (act == ACT_PRELU) { L.alpha_name = relu + "/alpha"; expect(h, L.alpha_name, {cout}); }
+  L.ep[act != ACT_NONE ? ST_ACT : ST_BN] = node_name ? node_name : "";
+  const int li = (int)h->layers.size();
+  h->layers.push_back(std::move(L));
+  Value v; v.cols = cout;
+  if (mode == 3) { v.frame_level = true; v.ctx = 0; } else { v.grid_F = Fout; }
+  const int vid = (int)h->values.size();
+  h->values.push_back(v);
+  Op op; op.kind = OP_GEMM; op.layer = li; op.in0 = in_value; op.in1 = residual_value; op.out = vid;
+  h->ops.push_back(op);
+  if (node_name) add_node(h, node_name, (int)h->ops.size() - 1, act != ACT_NONE ? ST_ACT : ST_BN);
+  return vid;
+}
+
+// model/resnet.py:152-351 (resnet_18): conv0, four stages of [conv_block, identity_block...], conv5,
+// dense1, dense2, pooling, tdnn6, tdnn7.  `channels` = width of stage 1 (64 in the reference).
+// Block outputs are exposed as extra nodes (conv0_relu, conv1a, ..., conv5_relu, dense*_relu) for
+// tests only; the reference registers just pooling / tdnn6_* / tdnn7_* / output.
+int build_resnet(xv_handle* h) {
+  const xv_model_desc& d = h->desc;
+  const int act = act_of(d);
+  const std::string sc = "resnet_18/";
+  if (d.feat_dim != 40) return fail(h, XV_ERR_INVALID, "resnet_18 needs 40-dim features (model/resnet.py:190)");
+  if (d.pooling_type != XV_POOL_STATISTICS)
+    return fail(h, XV_ERR_UNSUPPORTED, "resnet_18 registers no frame-level endpoints: only statistics_pooling is possible");
+  h->values.clear();
+  Value in; in.frame_level = true; in.ctx = 0; in.cols = 40;
+  h->values.push_back(in);
+  int F = 40, cin = d.channels;
+  int v = add_conv2d(h, sc + "conv0_1", sc + "conv0_bn", sc + "conv0_relu", 4, 1, cin, F, F, 1, act, 0, -1, "conv0_relu");
+  for (int stage = 1; stage <= 4; ++stage) {
+    const int nf = d.channels << (stage - 1);
+    const int sw = stage == 1 ? 1 : 2;
+    const int Fo = F / sw;
+    for (int bi = 0; bi < d.resnet_blocks[stage - 1]; ++bi) {
+      char nm[32];
+      if (bi == 0) snprintf(nm, sizeof(nm), "conv%da", stage); else snprintf(nm, sizeof(nm), "conv%db_%d", stage, bi - 1);
+      const std::string b = sc + nm;
+      const int s_w = bi == 0 ? sw : 1, Fi = bi == 0 ? F : Fo;
+      const int c0 = add_conv2d(h, b + "_conv0", b + "_bn0", b + "_relu0", 1, cin, nf, Fi, Fo, s_w, act, v, -1, nullptr);
+      int shortcut = v;
+      if (bi == 0)      // projection shortcut: 1x1 conv + BN (model/resnet.py:71-83)
+        shortcut = add_conv2d(h, b + "_conv_short", b + "_bn_short", "", 2, cin, nf, Fi, Fo, s_w, ACT_NONE, v, -1, nullptr);
+      v = add_conv2d(h, b + "_conv1", b + "_bn1", b + "_relu_final", 1, nf, nf, Fo, Fo, 1, act, c0, shortcut, nm);
+      cin = nf;
+    }
+    F = Fo;
+  }
+  v = add_conv2d(h, sc + "conv5", sc + "conv5_bn", sc + "conv5_relu", 3, cin, cin, F, 1, 1, act, v, -1, "conv5_relu");
+  h->final_ctx = 0;
+  // dense1 / dense2 (model/resnet.py:270-290): variables "<name>/kernel", BN "<name>_bn", PReLU "<name>_relu/alpha"
+  auto dense_named = [&](const char* name, int ci, int co, int in_v) {
+    Layer L;
+    L.kernel_name = sc + name + "/kernel"; L.bias_name = sc + name + "/bias";
+    L.w = 1; L.cin = ci; L.cout = co; L.has_bn = true; L.act = act;
+    expect(h, L.kernel_name, {ci, co}); expect(h, L.bias_name, {co});
+    L.bn_scope = sc + name + "_bn"; expect_bn(h, L.bn_scope, co);
+    if (act == ACT_PRELU) { L.alpha_name = sc + name + "_relu/alpha"; expect(h, L.alpha_name, {co}); }
+    L.ep[ST_ACT] = std::string(name) + "_relu";
+    const int li = (int)h->layers.size();
+    h->layers.push_back(std::move(L));
+    Value vv; vv.frame_level = true; vv.ctx = 0; vv.cols = co;
+    const int vid = (int)h->values.size();
+    h->values.push_back(vv);
+    Op op; op.kind = OP_GEMM; op.layer = li; op.in0 = in_v; op.out = vid;
+    h->ops.push_back(op);
+    add_node(h, std::string(name) + "_relu", (int)h->ops.size() - 1, ST_ACT);
+    return vid;
+  };
+  v = dense_named("dense1", cin, cin, v);
+  v = dense_named("dense2", cin, d.num_nodes_pooling_layer, v);
+  h->pool_dim = 2 * d.num_nodes_pooling_layer;
+  const int pooled = add_simple_op(h, OP_STAT_POOL, v, -1, false, 0, h->pool_dim);
+  add_node(h, "pooling", (int)h->ops.size() - 1, -1);
+  v = add_layer(h, sc + "tdnn6", "tdnn6", false, 1, h->pool_dim, cin, true, act, pooled, false, 0);
+  v = add_layer(h, sc + "tdnn7", "tdnn7", false, 1, cin, d.num_nodes_last_layer, !d.last_layer_no_bn,
+                d.last_layer_linear ? ACT_NONE : act, v, false, 0);
+  if (d.feature_norm) {
+    add_simple_op(h, OP_L2_SCALE, v, -1, false, 0, d.num_nodes_last_layer);
+    add_node(h, "output", (int)h->ops.size() - 1, -1);
+  } else {
+    const int last = (int)h->ops.size() - 1;
+    add_node(h, "output", last, h->layers[h->ops[last].layer].final_stage());
+  }
+  return XV_OK;
+}
+
 // Build the predict graph for `desc`: model/tdnn.py:36-181 (tdnn) or :343-591 (etdnn).
 int build_graph(xv_handle* h) {
   const xv_model_desc& d = h->desc;
+  if (d.network_type == XV_NET_RESNET18) return build_resnet(h);
   const int C = d.channels, act = act_of(d);
   h->values.clear();
   Value in; in.frame_level = true; in.ctx = 0; in.cols = d.feat_dim;
@@ -410,11 +521,12 @@ void bn_fold(const xv_handle* h, const std::string& scope, int n, std::vector<do
 }
 
 int upload_layer(xv_handle* h, Layer& L) {
-  const int K = L.w * L.cin, N = L.cout;
+  const int K = L.K(), N = L.cout;
   L.Kpad = (int)align_up(K, 32);
   L.Npad = (int)align_up(N, 128);
   const auto& W = T(h, L.kernel_name).data;      // [K][N] (HWIO flattened k-major / [in,out])
-  const auto& bias = T(h, L.bias_name).data;
+  const std::vector<float> no_bias((size_t)N, 0.f);      // resnet convs: use_bias=False (model/resnet.py:31)
+  const auto& bias = L.has_bias ? T(h, L.bias_name).data : no_bias;
   std::vector<float> vec((size_t)5 * N, 0.f);
   for (int n = 0; n < N; ++n) { vec[n] = bias[n]; vec[(size_t)4 * N + n] = 1.f; }
   if (L.has_bn) {
@@ -460,6 +572,7 @@ int upload_layer(xv_handle* h, Layer& L) {
 
 int64_t value_rows(const xv_handle* h, int vid, int64_t F0, int B) {
   const Value& v = h->values[vid];
+  if (v.grid_F > 0) return (F0 + 2 * (int64_t)B) * (v.grid_F + 2);
   return v.frame_level ? F0 - (int64_t)B * v.ctx : B;
 }
 
@@ -490,8 +603,12 @@ int xv_create(const xv_model_desc* desc, int device, xv_handle** out) {
   if (desc->struct_size != (int32_t)sizeof(xv_model_desc))
     return fail(nullptr, XV_ERR_INVALID, "xv_create: xv_model_desc size %d != %zu (ABI mismatch)", desc->struct_size,
                 sizeof(xv_model_desc));
-  if (desc->network_type != XV_NET_TDNN && desc->network_type != XV_NET_ETDNN)
-    return fail(nullptr, XV_ERR_UNSUPPORTED, "Not implement network_type %d (tdnn, extended_tdnn)", desc->network_type);
+  if (desc->network_type != XV_NET_TDNN && desc->network_type != XV_NET_ETDNN && desc->network_type != XV_NET_RESNET18)
+    return fail(nullptr, XV_ERR_UNSUPPORTED, "Not implement network_type %d (tdnn, extended_tdnn, resnet_18)", desc->network_type);
+  if (desc->network_type == XV_NET_RESNET18)
+    for (int i = 0; i < 4; ++i)
+      if (desc->resnet_blocks[i] < 1 || desc->resnet_blocks[i] > 16)
+        return fail(nullptr, XV_ERR_INVALID, "xv_create: resnet_blocks[%d] = %d", i, desc->resnet_blocks[i]);
   if (desc->feat_dim < 1 || desc->channels < 1 || desc->num_nodes_pooling_layer < 1 || desc->num_nodes_last_layer < 1)
     return fail(nullptr, XV_ERR_INVALID, "xv_create: non-positive layer width");
   if (desc->precision != XV_PREC_F32 && desc->precision != XV_PREC_BF16X3)
@@ -552,9 +669,13 @@ int xv_finalize(xv_handle* h) {
     if (op.kind != OP_GEMM) continue;
     Layer& L = h->layers[op.layer];
     const Value& vin = h->values[op.in0];
-    L.im2col = h->desc.precision == XV_PREC_BF16X3 && op.in0 == 0;
-    L.use_split = L.im2col || (h->desc.precision == XV_PREC_BF16X3 && vin.frame_level &&
-                               (L.w == 1 || L.cin % 32 == 0));
+    const bool bf = h->desc.precision == XV_PREC_BF16X3;
+    if (L.mode == 0) {
+      L.im2col = bf && op.in0 == 0;
+      L.use_split = L.im2col || (bf && vin.frame_level && (L.w == 1 || L.cin % 32 == 0));
+    } else {      // grid convolutions: whole SB blocks per tap; conv0 goes through its own im2col
+      L.use_split = bf && (L.mode == 4 || L.cin % 32 == 0);
+    }
   }
   for (auto& L : h->layers) {
     const int rc = upload_layer(h, L);
@@ -733,16 +854,23 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     if (op.kind == OP_GEMM) {
       const Layer& L = h->layers[op.layer];
       st.stage = st.to_out ? node.stage : L.final_stage();
-      st.M = (int)(st.rows_in - (L.w - 1));
-      if (L.w > 1) {
+      const int64_t padded_rows = F0 + 2 * (int64_t)batch;           // time rows incl. the two border rows per utterance
+      if (L.mode == 0) st.M = (int)(st.rows_in - (L.w - 1));
+      else if (L.mode == 1 || L.mode == 2) st.M = (int)(padded_rows * ((L.Fin + 2) / L.sw));
+      else if (L.mode == 3) st.M = (int)padded_rows;
+      else st.M = (int)(padded_rows * (L.Fout + 2));                 // conv0: one row per output grid position
+      if (L.w > 1 || L.mode != 0) {
         st.rowmap = (int)p->rowmap_off.size();
         p->rowmap_off.push_back(rowmap_elems);
         rowmap_elems += align_up(st.M, 64);
       }
-      st.flops = 2 * st.rows_out * (int64_t)L.cout * L.w * L.cin;
-      st.bytes = 4 * (st.rows_in * L.cin + st.rows_out * L.cout + (int64_t)L.w * L.cin * L.cout);
+      const int64_t valid_out = L.mode == 0 ? st.rows_out : F0 * (L.mode == 3 ? 1 : L.Fout);
+      st.flops = 2 * valid_out * (int64_t)L.cout * L.K();
+      st.bytes = 4 * (st.rows_in * L.cin + st.rows_out * L.cout + (int64_t)L.K() * L.cout);
       int64_t scratch = 0;
-      if (L.im2col) {
+      if (L.mode == 4) {
+        scratch = ((int64_t)st.M + kSlackRows) * 32 * 4;              // conv0 im2col rows (K = 9 padded to 32)
+      } else if (L.im2col) {
         scratch = (st.M + kSlackRows) * (int64_t)L.Kpad * 4;
       } else if (!L.use_split && op.out != fused_value) {
         st.ksplit = gemm_f32_ksplit(st.M, L.Kpad, L.Npad);
@@ -772,8 +900,13 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       vsize[op.out] = vsize[op.in0];
       vsize[op.in0] = 0;                 // ownership moves to the softmax value
       st.out_off = voff[op.out];
-    } else if (st.to_out && !node.att_weights) {
+    } else if (st.to_out && !node.att_weights && h->values[op.out].grid_F == 0) {
       st.out_off = -1;                   // straight into the caller's output buffer (fp32)
+    } else if (st.to_out && !node.att_weights) {
+      st.unpad_to_out = true;            // grid-valued node: padded grid in the workspace, then unpad into `out`
+      vsize[op.out] = value_bytes(h, op.out, F0, batch);
+      voff[op.out] = arena_alloc(vsize[op.out]);
+      st.out_off = voff[op.out];
     } else {
       if (op.out == fused_value) {
         st.fuse_pool = true;
@@ -817,6 +950,10 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     I.frame_level = 0;
     I.out_rows = (int64_t)batch * h->desc.att_num_heads;
     I.out_cols = p->uniform_L - vout.ctx;
+  } else if (vout.grid_F > 0) {
+    I.frame_level = 1;
+    I.out_rows = F0 * vout.grid_F;       // [sum L_b, F, C] without the border
+    I.out_cols = vout.cols;
   } else {
     I.frame_level = vout.frame_level ? 1 : 0;
     I.out_rows = value_rows(h, top.out, F0, batch);
@@ -843,8 +980,12 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       const Op& op = h->ops[st.op];
       const Layer& L = h->layers[op.layer];
       const int ctx_in = h->values[op.in0].ctx;
-      e = launch_build_rowmap(static_cast<const int32_t*>(p->d_offsets.p), batch, ctx_in, L.w,
-                              static_cast<int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.rowmap], st.M, s);
+      const int32_t* doff = static_cast<const int32_t*>(p->d_offsets.p);
+      int32_t* rm = static_cast<int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.rowmap];
+      if (L.mode == 0) e = launch_build_rowmap(doff, batch, ctx_in, L.w, rm, st.M, s);
+      else if (L.mode == 1 || L.mode == 2) e = launch_build_rowmap_grid(doff, batch, (L.Fin + 2) / L.sw, L.Fout, rm, st.M, s);
+      else if (L.mode == 3) e = launch_build_rowmap_rows(doff, batch, rm, st.M, s);
+      else e = launch_build_rowmap_interior(doff, batch, L.Fout, rm, st.M, s);
       if (e != hipSuccess) return bail(e, "build_rowmap");
     }
   }
@@ -947,6 +1088,22 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         a.alpha = (a.act == ACT_PRELU) ? L.d_alpha() : nullptr;
         a.rowmap = st.rowmap >= 0 ? static_cast<const int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.rowmap] : nullptr;
         a.Y = optr; a.ldy = L.cout;
+        a.K = L.K();
+        const Value& vo = h->values[op.out];
+        if (vo.grid_F > 0) {              // zero the border (and everything else) of a grid output first
+          if (st.out_off >= 0) XV_HIP(h, hipMemsetAsync(ws + st.out_off, 0, (size_t)st.rows_out * L.cout * 4, s));
+          if (st.out_sb_off >= 0) XV_HIP(h, hipMemsetAsync(ws + st.out_sb_off, 0, (size_t)st.rows_out * sb_ld(L.cout) * 4, s));
+        }
+        if (L.mode == 1 || L.mode == 2 || L.mode == 3) {      // A addressing on the input grid (csrc/grid.hip)
+          const int64_t Sin = L.Fin + 2;
+          a.a_pitch = (L.mode == 3 ? Sin : L.sw) * (int64_t)L.cin;
+          a.a_off = L.mode == 1 ? (L.sw == 1 ? 0 : L.cin) : (L.mode == 2 ? (Sin + 1) * L.cin : L.cin);
+          a.ntaps = L.mode == 1 ? 3 : 1;
+          a.ktap = L.mode == 1 ? 3 * L.cin : (L.mode == 2 ? L.cin : L.Fin * L.cin);
+          a.tap_stride = Sin * L.cin;
+          a.cin = a.K;                      // one "frame" per A row for the kernel's tap logic (w = 1)
+        }
+        if (op.in1 > 0) { a.R = in_ptr(st.in1_off); a.ldr = L.cout; }
         if (st.fuse_pool) {                 // statistics pooling partials instead of activations
           a.Y = nullptr;
           a.pool_part = reinterpret_cast<float*>(ws + st.out_off);
@@ -957,6 +1114,23 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           a.Ysb = ws + st.out_sb_off;
           a.ldsb = sb_ld(L.cout);
           if (st.out_off < 0 && !st.to_out) a.Y = nullptr;
+        }
+        if (L.mode == 4) {                  // conv0: 3x3 on the 1-channel input = im2col (9 taps, padded to 32) + dense GEMM
+          if (st.scratch_off < 0) return fail(h, XV_ERR_STATE, "conv0 has no scratch");
+          a.cin = 32; a.K = 32;             // taps 9..31 are zero in both operands
+          if (L.use_split) {
+            XV_HIP(h, launch_im2col2d_sb(feats, feat_ld, off, B, L.Fout, st.M, ws + st.scratch_off, s));
+            a.Xsb = ws + st.scratch_off; a.ldsbx = 32; a.Wsb = L.wsb.p;
+            XV_HIP(h, launch_gemm_bf16x3(a, s));
+          } else {
+            XV_HIP(h, launch_im2col2d_f32(feats, feat_ld, off, B, L.Fout, st.M, reinterpret_cast<float*>(ws + st.scratch_off), s));
+            a.X = reinterpret_cast<const float*>(ws + st.scratch_off); a.ldx = 32;
+            XV_HIP(h, launch_gemm_f32(a, true, s));
+          }
+          if (st.unpad_to_out)
+            XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.cols,
+                                          p->info.in_frames, out, s));
+          break;
         }
         if (L.im2col) {
           // 30-dim first layer on the split kernel: materialise the w*cin-wide rows once (SB
@@ -973,9 +1147,12 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         if (L.use_split) {
           if (st.in0_sb_off < 0) return fail(h, XV_ERR_STATE, "split layer %s has no split-blocked input", L.kernel_name.c_str());
           a.Xsb = ws + st.in0_sb_off;
-          a.ldsbx = sb_ld(L.cin);
+          a.ldsbx = L.mode == 0 ? sb_ld(L.cin) : 0;
           a.Wsb = L.wsb.p;
           XV_HIP(h, launch_gemm_bf16x3(a, s));
+          if (st.unpad_to_out)
+            XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.cols,
+                                          p->info.in_frames, out, s));
           break;
         }
         if (st.ksplit > 1 && st.scratch_off >= 0) {
@@ -983,7 +1160,12 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           a.partial = reinterpret_cast<float*>(ws + st.scratch_off);
         }
         const bool aligned = op.in0 != 0 && (a.ldx % 4 == 0) && (a.K % 4 == 0);
+        if (L.mode != 0 && !aligned)
+          return fail(h, XV_ERR_UNSUPPORTED, "resnet convolution %s needs channel counts that are multiples of 4", L.kernel_name.c_str());
         XV_HIP(h, launch_gemm_f32(a, aligned, s));
+        if (st.unpad_to_out)
+          XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.cols,
+                                        p->info.in_frames, out, s));
         break;
       }
       case OP_STAT_POOL: {

@@ -127,6 +127,68 @@ def synth_weights(params, dim, seed=0, channels=512):
     return w
 
 
+def synth_resnet_weights(params, seed=0, width=64):
+    """Variables of model/resnet.py:152-351 (scope "resnet_18").  `width` = channels of stage 1
+    (64 in the reference; stages are width, 2w, 4w, 8w; the dense/segment layers use 8w and
+    num_nodes_pooling_layer); tests shrink it."""
+    rs = np.random.RandomState(seed)
+    w = OrderedDict()
+    sc = "resnet_18"
+    blocks = list(_get(params, "resnet_blocks", [2, 2, 2, 2]))
+    pool_nodes = int(_get(params, "num_nodes_pooling_layer", 1500))
+    last_nodes = int(_get(params, "num_nodes_last_layer", 512))
+
+    def conv(name, kh, kw, cin, cout, bias=False):
+        w["%s/%s/kernel" % (sc, name)] = _glorot(rs, (kh, kw, cin, cout))
+        if bias:
+            w["%s/%s/bias" % (sc, name)] = (0.1 * rs.standard_normal(cout)).astype(np.float32)
+
+    def bn_act(bn_name, relu_name, n):
+        _bn(rs, w, "%s/%s" % (sc, bn_name), n)
+        if relu_name:
+            _prelu(rs, w, "%s/%s" % (sc, relu_name), n, params)
+
+    conv("conv0_1", 3, 3, 1, width)
+    bn_act("conv0_bn", "conv0_relu", width)
+    cin = width
+    for stage in (1, 2, 3, 4):
+        nf = width << (stage - 1)
+        names = ["conv%da" % stage] + ["conv%db_%d" % (stage, i) for i in range(blocks[stage - 1] - 1)]
+        for bi, name in enumerate(names):
+            conv(name + "_conv0", 3, 3, cin, nf)
+            bn_act(name + "_bn0", name + "_relu0", nf)
+            conv(name + "_conv1", 3, 3, nf, nf)
+            bn_act(name + "_bn1", None, nf)
+            if bi == 0:
+                conv(name + "_conv_short", 1, 1, cin, nf)
+                bn_act(name + "_bn_short", None, nf)
+            _prelu(rs, w, "%s/%s_relu_final" % (sc, name), nf, params)
+            cin = nf
+    c8 = width << 3
+    conv("conv5", 1, 5, c8, c8, bias=True)
+    bn_act("conv5_bn", "conv5_relu", c8)
+    for name, a, b in (("dense1", c8, c8), ("dense2", c8, pool_nodes), ("tdnn6_dense", 2 * pool_nodes, c8),
+                       ("tdnn7_dense", c8, last_nodes)):
+        w["%s/%s/kernel" % (sc, name)] = _glorot(rs, (a, b))
+        w["%s/%s/bias" % (sc, name)] = (0.1 * rs.standard_normal(b)).astype(np.float32)
+    bn_act("dense1_bn", "dense1_relu", c8)
+    bn_act("dense2_bn", "dense2_relu", pool_nodes)
+    bn_act("tdnn6_bn", "tdnn6_relu", c8)
+    if not _get(params, "last_layer_no_bn", False):
+        _bn(rs, w, sc + "/tdnn7_bn", last_nodes)
+    if not _get(params, "last_layer_linear", False):
+        _prelu(rs, w, sc + "/tdnn7_relu", last_nodes, params)
+    return w
+
+
+RESNET_PARAMS = {             # egs/voxceleb/v3/nnet_conf/resnet18_softmax_1e-2.json (hot-path keys)
+    "seed": 0, "network_type": "resnet_18", "resnet_time_stride": False, "resnet_maxpooling": False,
+    "last_layer_linear": False, "loss_func": "softmax", "pooling_type": "statistics_pooling",
+    "embedding_node": "tdnn6_dense", "weight_l2_regularizer": 1e-2, "batchnorm_momentum": 0.99,
+    "keep_checkpoint_max": 10,
+}
+
+
 def synth_features(num, frames, dim, seed=1234):
     """Post-CMVN-like features: N(0,1) float32.  `frames` is an int (uniform) or a sequence
     of per-utterance lengths.  Returns a list of [T,dim] arrays."""

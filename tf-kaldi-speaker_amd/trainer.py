@@ -26,7 +26,7 @@ def _relu_type(params):
     return {"prelu": _lib.XV_ACT_PRELU, "lrelu": _lib.XV_ACT_LRELU}.get(t, _lib.XV_ACT_RELU)
 
 
-_NETWORK_TYPES = {"tdnn": 0, "extended_tdnn": 1}          # XV_NET_* (model/trainer.py:100-110)
+_NETWORK_TYPES = {"tdnn": 0, "extended_tdnn": 1, "resnet_18": 2}          # XV_NET_* (model/trainer.py:100-110)
 
 
 def _endpoint_index(name, what):
@@ -47,8 +47,8 @@ class Trainer(object):
         # model/trainer.py:100-110 network dispatch.  Only the TDNN is on this round's hot path.
         self.network_type = params.network_type
         if params.network_type not in _NETWORK_TYPES:
-            if params.network_type in ("tdnn-s", "resnet_18"):
-                raise NotImplementedError("%s network is not built yet (SURVEY.md 8a16 / 8f)" % params.network_type)
+            if params.network_type == "tdnn-s":
+                raise NotImplementedError("tdnn-s is dead code in the reference (quit() at model/tdnn.py:201-202)")
             raise NotImplementedError("Not implement %s network" % params.network_type)
         self.params = params
         self.model = os.path.join(model_dir, "nnet") if model_dir is not None else None
@@ -88,6 +88,15 @@ class Trainer(object):
             p.dict["last_layer_linear"] = False
         if p.pooling_type not in ("statistics_pooling", "self_attention"):
             raise NotImplementedError("Not implement %s pooling" % p.pooling_type)     # model/pooling.py:23
+        if p.network_type == "resnet_18":
+            if self.dim != 40:
+                raise AssertionError("resnet_18 needs 40-dim features (model/resnet.py:190)")
+            if p.dict.get("resnet_time_stride", False) or p.dict.get("resnet_maxpooling", False):
+                raise NotImplementedError("resnet_time_stride / resnet_maxpooling are not built")
+            if "resnet_blocks" not in p.dict:
+                p.dict["resnet_blocks"] = [2, 2, 2, 2]                                  # model/resnet.py:203-204
+            if p.pooling_type != "statistics_pooling":
+                raise NotImplementedError("resnet_18 registers no frame-level endpoints for attention (model/resnet.py)")
         if "feature_norm" in p.dict and p.feature_norm:
             assert "feature_scaling_factor" in p.dict, \
                 "If feature normalization is applied, scaling factor is necessary."      # trainer.py:401
@@ -115,6 +124,8 @@ class Trainer(object):
         d.feature_norm = int(bool(p.dict.get("feature_norm", False)))
         d.feature_scaling_factor = float(p.dict.get("feature_scaling_factor", 1.0))
         d.precision = _PRECISIONS[self._precision]
+        for i, n in enumerate(p.dict.get("resnet_blocks", [2, 2, 2, 2])):
+            d.resnet_blocks[i] = int(n)
         if p.pooling_type == "self_attention":
             kn = list(p.att_key_num_nodes)
             vn = list(p.att_value_num_nodes)
@@ -160,8 +171,11 @@ class Trainer(object):
         self._torch = torch
         self._lib = _lib.load()
         self._release()
-        scope = "etdnn" if self.params.network_type == "extended_tdnn" else "tdnn"
-        k1 = np.asarray(weights[scope + "/tdnn1_conv/kernel"])
+        if self.params.network_type == "resnet_18":
+            k1 = np.asarray(weights["resnet_18/conv0_1/kernel"])          # [3,3,1,width]
+        else:
+            scope = "etdnn" if self.params.network_type == "extended_tdnn" else "tdnn"
+            k1 = np.asarray(weights[scope + "/tdnn1_conv/kernel"])
         desc = self._make_desc(channels=k1.shape[-1])
         h = C.c_void_p()
         _lib.check(self._lib.xv_create(C.byref(desc), self._device_index, C.byref(h)))
@@ -301,6 +315,8 @@ class Trainer(object):
             emb = out.cpu().numpy()
         if node == "attention_weights":
             emb = emb.reshape(b, -1, emb.shape[-1])
+        elif info.frame_level and emb.shape[0] > b * t:       # ResNet block output [b, l, f, c] (test-only nodes)
+            emb = emb.reshape(b, t, -1, emb.shape[-1])
         elif info.frame_level:
             emb = emb.reshape(b, -1, emb.shape[-1])
         if rank == 2:
