@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--dim", type=int, default=30)
     ap.add_argument("--precision", default=os.environ.get("XVEC_PRECISION", ""), help="f32 | bf16x3 (default: library default)")
     ap.add_argument("--pooling", default="statistics_pooling", choices=["statistics_pooling", "self_attention"])
+    ap.add_argument("--network", default="tdnn", choices=["tdnn", "extended_tdnn", "resnet_18"],
+                    help="tdnn = BASELINE configs 1-4; resnet_18 = config 5 (use --dim 40 --batch 64)")
     ap.add_argument("--varlen", action="store_true", help="config 4: T ~ U[200,1000] (seed 2024)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent timing")
@@ -51,7 +53,8 @@ def pmc_traffic(kernel, precision, args):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
     command (profiles/<round>/traffic.json; FETCH_SIZE/WRITE_SIZE need their own profiler runs, so
     they cannot be sampled inside the timed region).  None when no matching profile exists."""
-    if precision != "bf16x3" or args.varlen or args.pooling != "statistics_pooling" or args.batch != 256 or args.frames != 300:
+    if (precision != "bf16x3" or args.varlen or args.pooling != "statistics_pooling" or args.batch != 256 or
+            args.frames != 300 or args.network != "tdnn"):
         return None
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
@@ -73,7 +76,7 @@ def cpu_baseline(weights, params, dim, frames, budget_s):
     prev = torch.get_num_threads()
     torch.set_num_threads(1)
     try:
-        model = ref_torch.TorchTdnn(weights, params)
+        model = (ref_torch.TorchResnet18 if params.network_type == "resnet_18" else ref_torch.TorchTdnn)(weights, params)
         utts = synth.synth_features(4, frames, dim, seed=99)
         model.predict(utts[0], dim)                       # warm-up
         n, t0 = 0, time.perf_counter()
@@ -114,8 +117,18 @@ def main():
     precision = args.precision or trainer_mod.DEFAULT_PRECISION
 
     base = synth.TDNN_ATT_PARAMS if args.pooling == "self_attention" else synth.TDNN_STAT_PARAMS
-    params = Params(**dict(base))
-    weights = synth.synth_weights(params, args.dim, seed=0)
+    if args.network == "resnet_18":
+        if args.dim != 40:
+            args.dim = 40
+        params = Params(**dict(synth.RESNET_PARAMS))
+        weights = synth.synth_resnet_weights(params, seed=0)
+    else:
+        params = Params(**dict(base, network_type=args.network))
+        if args.network == "extended_tdnn":
+            params.embedding_node = "tdnn12_dense"
+            if args.pooling == "self_attention":
+                params.att_key_input, params.att_value_input = "tdnn9_relu", "tdnn10_relu"
+        weights = synth.synth_weights(params, args.dim, seed=0)
     tr = Trainer(params, None, args.dim, single_cpu=True, device=local_rank, precision=precision)
     tr.build("predict")
     tr.load_weights(weights)
@@ -143,7 +156,7 @@ def main():
         step()
     sync_dev()
     if not args.no_profile:
-        tr.profile_begin(max_events=2 * 16 * (args.steps + 1))
+        tr.profile_begin(max_events=2 * 48 * (args.steps + 1))
     # barrier + synchronize, exactly K steps, barrier + synchronize, max over ranks
     elapsed = sharding.timed_steps(step, args.steps, sync_dev, dist=dist if world > 1 else None, device=dev)
     kernels = []
@@ -156,7 +169,7 @@ def main():
         value = total_utts / elapsed
         # parity spot check against the float64 oracle on a few utterances of this batch
         from oracle import ref_numpy
-        idx = list(range(0, args.batch, max(1, args.batch // 4)))[:4]
+        idx = list(range(0, args.batch, max(1, args.batch // 4)))[:(2 if args.network == "resnet_18" else 4)]
         errs = []
         for i in idx:
             ref = ref_numpy.predict(utts[i], weights, params, args.dim)
@@ -183,8 +196,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if precision == "f32" else "bf16x3(f32-split)", "data": "synthetic",
-            "config": {"workload": "TDNN x-vector (tdnn6_dense), %s, %d utt/GPU/step of %s frames x %d dims"
-                       % (args.pooling, args.batch, "U[200,1000]" if args.varlen else str(args.frames), args.dim),
+            "config": {"workload": "%s x-vector (%s), %s, %d utt/GPU/step of %s frames x %d dims"
+                       % (args.network, params.embedding_node, args.pooling, args.batch,
+                          "U[200,1000]" if args.varlen else str(args.frames), args.dim),
                        "batch_per_gpu": args.batch, "frames": "varlen" if args.varlen else args.frames,
                        "node": params.embedding_node, "precision": precision, "parallelism": "utterance-shard x%d" % n_gpus},
             "tflops_algorithmic": round(flops_step * args.steps * n_gpus / elapsed / 1e12, 2),

@@ -1026,7 +1026,14 @@ void xv_plan_destroy(xv_plan* p) {
 static const char* step_name(const xv_handle* h, const PlanStep& st) {
   const Op& op = h->ops[st.op];
   switch (op.kind) {
-    case OP_GEMM: return h->layers[op.layer].ep[ST_AFFINE].c_str();
+    case OP_GEMM: {
+      const Layer& L = h->layers[op.layer];
+      if (!L.ep[ST_AFFINE].empty()) return L.ep[ST_AFFINE].c_str();
+      const size_t a = L.kernel_name.find('/'), b = L.kernel_name.rfind('/');      // "resnet_18/conv1a_conv0/kernel"
+      static thread_local std::string tmp;
+      tmp = (a != std::string::npos && b > a) ? L.kernel_name.substr(a + 1, b - a - 1) : L.kernel_name;
+      return tmp.c_str();
+    }
     case OP_STAT_POOL: return "stat_pool";
     case OP_ATT_SCORES: return "att_scores";
     case OP_ATT_SOFTMAX: return "att_softmax";
