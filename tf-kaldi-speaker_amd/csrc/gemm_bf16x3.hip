@@ -140,15 +140,28 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 }  // namespace
 
-template <int SCHED>
-__global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int nMt, int nNt, int w, int diag) {
+// WS = warp-specialised form: 384 threads, waves 0-3 are CONSUMERS (ds_read + MFMA + epilogue only)
+// and waves 4-5 LOADERS that only issue the DMA of the next step and then wait at the barrier
+// (two loaders: 3 waves per SIMD with two workgroups per CU keeps a 168-VGPR budget).  An
+// LDS-DMA piece costs the issuing wave 60-185 issue cycles (MI355X_MICROARCH.md), ~4.6 pieces per
+// wave per step next to a 768-cycle MFMA phase; the idea was to let the consumer stream run in the
+// "ds_read + MFMA only" regime of the ablation.  MEASURED: 2.3x slower (L3 1.59 vs 0.69 ms) -- one
+// wave's stream of 9 LDS-DMA pieces takes ~3 us to land, so the pieces must stay spread over all
+// waves.  Kept only as an A/B variant (XVEC_GEMM_SCHED=2); WS = false is the product path.
+template <bool WS>
+__global__ __launch_bounds__(WS ? 384 : 256, WS ? 3 : 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int nMt, int nNt, int w,
+                                                                                     int diag) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   char* As = smem3;                      // [2][DA_ROWS][128]
   char* Bs = smem3 + 2 * DA_BYTES;       // [2][BN][128]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = WS && wave_id >= 4;          // wave-uniform role
+  const bool loads = !WS || loader, computes = !WS || !loader;
+  const int wave = wave_id & 3;                    // index inside the role (tile quadrant / DMA share)
+  constexpr int NL = WS ? 2 : 4;                   // waves that share the DMA work
   const int wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
 
@@ -193,11 +206,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // prologue: whole slab 0 and the weight tile of step 0
-  for (int g = wave; g < ngroups; g += 4) dma_a(0, 0, g);
+  if (loads)
+    for (int g = wave; g < ngroups; g += NL) dma_a(0, 0, g);
   int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : 128;   // K-block offset of slab cb + 1
   int blk_next = (kbt == 1 && p.a_pitch) ? 0 : 1;                  // its block index inside the tap
+  if (loads) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dma_b(0, 0, wave + 4 * q);
+    for (int q = 0; q < 16 / NL; ++q) dma_b(0, 0, wave + NL * q);
+  }
   __syncthreads();
 
   // B fragment offsets (row fixed per lane): chunk c = plane*4 + ks*2 + h
@@ -214,16 +230,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
   for (int s = 0; s < nsteps; ++s) {
     int cb_next = cb, j_next = j + 1;
     if (j_next == w) { j_next = 0; cb_next = cb + 1; }
-    if (s + 1 < nsteps && !(diag & 4)) {   // diag bit2: no weight DMA in the loop (timing only)
+    if (loads && s + 1 < nsteps && !(diag & 4)) {   // diag bit2: no weight DMA in the loop (timing only)
       const int kb = (diag & 32) ? 0 : j_next * ncb + cb_next;   // diag bit5: always the same (L2-hot) source tile
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dma_b(kb, (s + 1) & 1, wave + 4 * q);
+      for (int q = 0; q < 16 / NL; ++q) dma_b(kb, (s + 1) & 1, wave + NL * q);
     }
-    if (cb + 1 < ncb && !(diag & 8)) {     // diag bit3: no slab DMA in the loop (timing only)
+    if (loads && cb + 1 < ncb && !(diag & 8)) {     // diag bit3: no slab DMA in the loop (timing only)
       const int gend = min((j + 1) * gps, ngroups);
-      for (int g = j * gps + wave; g < gend; g += 4) dma_a((diag & 32) ? 0 : koff_next, (cb + 1) & 1, g);
+      for (int g = j * gps + wave; g < gend; g += NL) dma_a((diag & 32) ? 0 : koff_next, (cb + 1) & 1, g);
     }
 
+    if (computes) {
     const char* ab = As + (cb & 1) * DA_BYTES;
     const char* bb = Bs + (s & 1) * DB_BYTES;
     int aoff[2], aswz[2];
@@ -254,17 +271,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
           acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ks][nj], ah[ks][mi], acc[nj][mi], 0, 0, 0);
           acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks][nj], ah[ks][mi], acc[nj][mi], 0, 0, 0);
         }
-    if (SCHED == 1) {   // all 16 fragment reads first, then the 24 MFMAs back to back
-      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
-    } else if (SCHED == 2) {   // ks=0 reads, ks=1 reads interleaved with the ks=0 MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     }
     if (!(diag & 16)) __syncthreads();     // diag bit4: no barrier (timing only, racy)
     if (cb_next != cb) {                 // advance the A K-block offset with the slab index
@@ -279,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
     j = j_next;
   }
 
+  if (loader) return;     // loaders are done; s_barrier waits only on the surviving waves of the workgroup
   if (diag & 2) {       // diag bit1: skip the epilogue stores (keep the accumulators live)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -453,7 +460,7 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   static int force = -1;        // XVEC_GEMM_TILE=128 register-staged | 1 DMA 128x128 | 256 pipelined 256x128; 0 = by size
   static bool attr_set = false;
-  static int sched = 0, diag = 0;   // XVEC_GEMM_SCHED / XVEC_GEMM_DIAG: tuning & timing-only switches
+  static int sched = 0, diag = 0;   // XVEC_GEMM_SCHED=2: warp-specialised variant; XVEC_GEMM_DIAG: timing-only switches
   const size_t smem128 = (size_t)4 * TILE_B;
   const size_t smemdma = (size_t)2 * DA_BYTES + 2 * DB_BYTES;
   const size_t smempipe = (size_t)3 * PA_BYTES + 3 * PB_BYTES;
@@ -463,9 +470,8 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
     if (r != hipSuccess) return r;
-    for (const void* f : {reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<0>),
-                          reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<1>),
-                          reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<2>)}) {
+    for (const void* f : {reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<false>),
+                          reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<true>)}) {
       r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemdma);
       if (r != hipSuccess) return r;
     }
@@ -487,12 +493,10 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
   }
   if (force != 128 && taps_ok) {
     const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
-    if (sched == 1)
-      hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<1>, dim3(nMt * nNt), dim3(256), smemdma, s, a, nMt, nNt, w, diag);
-    else if (sched == 2)
-      hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<2>, dim3(nMt * nNt), dim3(256), smemdma, s, a, nMt, nNt, w, diag);
+    if (sched == 2)     // XVEC_GEMM_SCHED=2: warp-specialised A/B variant (measured 2.3x SLOWER: profiles/README.md)
+      hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<true>, dim3(nMt * nNt), dim3(384), smemdma, s, a, nMt, nNt, w, diag);
     else
-      hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<0>, dim3(nMt * nNt), dim3(256), smemdma, s, a, nMt, nNt, w, diag);
+      hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<false>, dim3(nMt * nNt), dim3(256), smemdma, s, a, nMt, nNt, w, diag);
     return hipGetLastError();
   }
   const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
