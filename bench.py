@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--varlen", action="store_true", help="config 4: T ~ U[200,1000] (seed 2024)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent timing")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the forward from a captured hipGraph (per-kernel events are then not recorded)")
     return ap.parse_args()
 
 
@@ -149,8 +151,16 @@ def main():
     def sync_dev():
         torch.cuda.synchronize(dev)
 
+    graph = None
+    if args.graph:
+        graph, _ = tr.capture_graph(feats, offsets, out=out)
+        args.no_profile = True
+
     def step():
-        tr.predict_packed(feats, offsets, out=out)
+        if graph is not None:
+            graph.replay()
+        else:
+            tr.predict_packed(feats, offsets, out=out)
 
     for _ in range(args.warmup):
         step()
@@ -162,6 +172,14 @@ def main():
     kernels = []
     if not args.no_profile:
         kernels, _ = tr.profile_end()
+    # extra leg (not `value`): the same K steps replayed from a captured hipGraph
+    graph_rate = None
+    if graph is None and not args.varlen:
+        g2, _ = tr.capture_graph(feats, offsets, out=out)
+        for _ in range(args.warmup):
+            g2.replay()
+        el2 = sharding.timed_steps(g2.replay, args.steps, sync_dev, dist=dist if world > 1 else None, device=dev)
+        graph_rate = n_gpus * args.batch * args.steps / el2
     result = None
     if rank == 0:
         emb = out.cpu().numpy()
@@ -200,8 +218,10 @@ def main():
                        % (args.network, params.embedding_node, args.pooling, args.batch,
                           "U[200,1000]" if args.varlen else str(args.frames), args.dim),
                        "batch_per_gpu": args.batch, "frames": "varlen" if args.varlen else args.frames,
-                       "node": params.embedding_node, "precision": precision, "parallelism": "utterance-shard x%d" % n_gpus},
+                       "node": params.embedding_node, "precision": precision, "parallelism": "utterance-shard x%d" % n_gpus,
+                       "launch": "hipGraph replay" if args.graph else "stream launches"},
             "tflops_algorithmic": round(flops_step * args.steps * n_gpus / elapsed / 1e12, 2),
+            "graph_replay_value": round(graph_rate, 1) if graph_rate else None,
             "parity_rel_l2_max": max(errs),
             "kernels": [{"name": k["name"], "ms": round(k["ms"], 4),
                          "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["ms"] > 0 else None,

@@ -69,6 +69,7 @@ class Trainer(object):
         self._plans = {}
         self._ws = None
         self._step = None
+        self._torch = None
 
     # ------------------------------------------------------------------ graph build
     def build(self, mode, noupdate_var_list=None):
@@ -258,6 +259,26 @@ class Trainer(object):
                 C.c_void_p(out.data_ptr()), out.numel(), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream))
         _lib.check(self._lib.xv_forward(*args), self._h)
         return out
+
+    def capture_graph(self, feats_dev, offsets, node=None, out=None):
+        """Capture one forward (xv_forward only enqueues kernels: no allocation, no host sync) into a
+        hipGraph and return (graph, out).  `graph.replay()` re-runs it on the current stream with the
+        same buffers; refill `feats_dev` in place between replays."""
+        torch = self._torch if self._torch is not None else __import__("torch")
+        if not self.is_loaded:
+            self._lazy_load()
+        node = node or self.embeddings
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        _, info = self._plan(offsets, node)                # plan + workspace exist before the capture starts
+        self._workspace(info.workspace_bytes + 256)
+        if out is None:
+            out = torch.empty((int(info.out_rows), int(info.out_cols)), dtype=torch.float32, device=feats_dev.device)
+        self.predict_packed(feats_dev, offsets, node, out=out)         # warm-up outside the capture
+        torch.cuda.synchronize(feats_dev.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.predict_packed(feats_dev, offsets, node, out=out)
+        return graph, out
 
     def profile_begin(self, max_events=4096):
         """Start per-kernel hipEvent timing of the following predict calls (bench.py)."""
