@@ -60,3 +60,49 @@ def test_scp_rspecifier_is_refused(tmp_path, repo_root):
     r = subprocess.run([sys.executable, "-m", "tf_kaldi_speaker_amd.extract", model_dir, "feats.scp", "ark:out.ark"],
                        env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "rspecifier must be ark" in r.stderr
+
+
+def test_extract_frame_and_attention_cli(tmp_path, repo_root):
+    """extract_frame.py / extract_attention.py surfaces end to end (matrix ark out)."""
+    from tf_kaldi_speaker_amd import extract_frame, kaldi_io, model_io, synth
+    params = dict(synth.TDNN_ATT_PARAMS, num_nodes_pooling_layer=96, att_key_num_nodes=[64, 48], att_num_heads=2,
+                  embedding_node="tdnn6_dense")
+    weights = synth.synth_weights(params, 30, seed=3, channels=64)
+    weights["tdnn/attention/query"] = weights["tdnn/attention/query"] * 50.0
+    model_dir = str(tmp_path / "exp")
+    model_io.save_model(model_dir, params, 30, weights, step=7)
+    lens = [20, 40, 130, 77]
+    utts = synth.synth_features(len(lens), lens, 30, seed=9)
+    ark = str(tmp_path / "feats.ark")
+    with open(ark, "wb") as f:
+        for i, u in enumerate(utts):
+            kaldi_io.write_mat(f, u, key="u%d" % i)
+    env = dict(os.environ, PYTHONPATH=repo_root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out_f = str(tmp_path / "frames.ark")
+    r = subprocess.run([sys.executable, "-m", "tf_kaldi_speaker_amd.extract_frame", "--gpu", "0", "--node", "tdnn4_relu",
+                        "--chunk-size", "50", "--precision", "f32", model_dir, "ark:" + ark, "ark:" + out_f],
+                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = dict(kaldi_io.read_mat_ark(out_f))
+    assert list(got) == ["u1", "u2", "u3"]
+    for i in (1, 2, 3):
+        u = utts[i]
+        parts = []
+        for s0, n in extract_frame.split_plain(u.shape[0], 50) if u.shape[0] > 50 else [(0, u.shape[0])]:
+            e = ref_numpy.predict(u[s0:s0 + n], weights, params, 30, node="tdnn4_relu")
+            parts.append(extract_frame.pad_edges(e, n))
+        ref = np.concatenate(parts, axis=0)
+        assert got["u%d" % i].shape == (u.shape[0], 64)
+        assert np.linalg.norm(got["u%d" % i] - ref) / np.linalg.norm(ref) <= 1e-4
+    out_a = str(tmp_path / "att.ark")
+    r = subprocess.run([sys.executable, "-m", "tf_kaldi_speaker_amd.extract_attention", "--gpu", "0", "--chunk-size", "100",
+                        "--precision", "f32", model_dir, "ark:" + ark, "ark:" + out_a],
+                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    att = dict(kaldi_io.read_mat_ark(out_a))
+    assert list(att) == ["u1", "u2", "u3"]
+    for i in (1, 2, 3):
+        u = utts[i][:100]
+        ref = ref_numpy.predict(u, weights, params, 30, node="attention_weights")
+        assert att["u%d" % i].shape == ref.shape == (2, u.shape[0] - 14)
+        assert np.linalg.norm(att["u%d" % i] - ref) / np.linalg.norm(ref) <= 1e-4

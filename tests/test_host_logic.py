@@ -137,3 +137,31 @@ def test_trainer_refuses_unsupported_graphs_and_missing_gpu():
         tr.build("predict")
         with pytest.raises(RuntimeError):                       # no silent CPU fallback
             tr.load_weights(synth.synth_weights(synth.TDNN_STAT_PARAMS, 30, channels=8))
+
+
+def test_extract_frame_stream_padding_and_chunking():
+    """egs/voxceleb/v1/nnet/lib/extract_frame.py:64-94 with a stand-in network of context 14."""
+    from tf_kaldi_speaker_amd import extract_frame
+
+    def embed(utts):              # frame-level stand-in: valid window of 15 frames -> T - 14 rows
+        return [np.stack([u[t:t + 15].mean(0) for t in range(u.shape[0] - 14)]) for u in utts]
+
+    lens = [24, 25, 40, 100, 130, 230]     # (a trailing chunk shorter than the context fails in the reference too)
+    items = [("u%d" % i, u) for i, u in enumerate(synth.synth_features(len(lens), lens, 4, seed=2))]
+    out = []
+    done, skipped = extract_frame.extract_frames_stream(embed, iter(items), lambda k, m: out.append((k, m)),
+                                                        min_chunk_size=25, chunk_size=100, batch_frames=150)
+    assert (done, skipped) == (5, 1) and [k for k, _ in out] == ["u1", "u2", "u3", "u4", "u5"]
+    for (k, m), (_, f) in zip(out, items[1:]):
+        assert m.shape == (f.shape[0], 4) and m.dtype == np.float32
+    # reference arithmetic for one chunked utterance (T=230, S=100: chunks 100, 100, 30)
+    f = items[5][1]
+    parts = []
+    for s0, n in ((0, 100), (100, 100), (200, 30)):
+        e = embed([f[s0:s0 + n]])[0]
+        pad = (n - e.shape[0]) // 2
+        parts.append(np.concatenate([np.tile(e[0], [pad, 1]), e, np.tile(e[-1], [pad, 1])], axis=0))
+    np.testing.assert_allclose(out[4][1], np.concatenate(parts, axis=0), rtol=1e-6)
+    assert extract_frame.split_plain(230, 100) == [(0, 100), (100, 100), (200, 30)]
+    a = extract_frame.build_parser().parse_args(["--node", "tdnn4_relu", "m", "r", "w"])
+    assert (a.gpu, a.min_chunk_size, a.chunk_size, a.node) == (-1, 25, 10000, "tdnn4_relu")
