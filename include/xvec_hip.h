@@ -172,6 +172,30 @@ typedef struct {
 int xv_profile_begin(xv_handle* h, int max_events);
 int xv_profile_end(xv_handle* h, xv_kernel_time* entries, int max_entries, int* n_forwards);
 
+/* ---- host-side ark I/O (csrc/ark_io.cpp; no HIP calls, usable without a GPU) ---------------------
+ * Batch counterpart of dataset/kaldi_io.py read_mat_ark (:974-994, records per _read_mat_binary
+ * :1014-1031 / _read_compressed_mat :1071-1115) and write_vec_flt (:915-946): the extraction driver
+ * (extract.py:64,93) reads and writes one record per Python call; these parse / format a whole batch. */
+typedef struct xv_ark_reader xv_ark_reader;
+/* Open a binary matrix ark by path, or wrap an already open descriptor (path == NULL; e.g. the read
+ * end of a `cmd |` rspecifier pipe).  The descriptor is closed by xv_ark_close only when opened here. */
+int xv_ark_open(const char* path, int fd, xv_ark_reader** out);
+/* Read consecutive utterances ('FM ', 'DM ', 'CM ' records) until `max_frames` frames or `max_utts`
+ * utterances are collected or the next one does not fit.  Utterances with fewer than `min_frames` rows
+ * are dropped and counted (extract.py:65-67).  dst: float32 [frames, dim] row-major, utterance i =
+ * rows offsets[i]..offsets[i+1]; keys: '\n'-terminated keys back to back.  Returns the number of
+ * utterances (0 = end of stream) or a negative status code; the message is xv_ark_error(r). */
+int xv_ark_next_batch(xv_ark_reader* r, int64_t max_frames, int max_utts, int min_frames, float* dst,
+                      int64_t dst_capacity, int32_t* offsets, char* keys, int64_t keys_capacity, int* n_utts,
+                      int* dim);
+int64_t xv_ark_skipped(const xv_ark_reader* r);
+const char* xv_ark_error(const xv_ark_reader* r);
+void xv_ark_close(xv_ark_reader* r);
+/* Format n float vectors (row i = data + i*ld, `dim` values) as binary Kaldi vector records
+ * "key SP \0B FV \4 <i32 dim> payload" into `out`; returns the byte count or a negative xv_status. */
+int64_t xv_ark_format_vectors(const char* keys, int n, const float* data, int dim, int64_t ld, char* out,
+                              int64_t out_capacity);
+
 /* Trainer.close (model/trainer.py:270-275). */
 void xv_destroy(xv_handle* h);
 

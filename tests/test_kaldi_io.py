@@ -96,3 +96,77 @@ def test_sequential_reads_on_caller_owned_descriptor():
     assert kaldi_io.read_key(buf) == "u2"
     assert kaldi_io.read_mat(buf).shape == (1, 2)
     assert kaldi_io.read_key(buf) is None
+
+
+# ------------------------------------------------------------------ native batch reader / formatter (csrc/ark_io.cpp)
+@pytest.fixture(scope="module")
+def native():
+    import __graft_entry__ as g
+    g.build()
+    from tf_kaldi_speaker_amd import native_ark
+    return native_ark
+
+
+def test_native_reader_decodes_reference_fixture(native):
+    """FM / DM / CM records of tests/golden/feats.ark (written / decoded by the reference's kaldi_io.py)."""
+    exp = np.load(os.path.join(GOLD, "feats_expected.npz"))
+    got = []
+    for keys, off, feats in native.ArkBatchReader(os.path.join(GOLD, "feats.ark"), batch_frames=1000):
+        for i, k in enumerate(keys):                       # the three records differ in width -> one batch each
+            got.append((k, feats[off[i]:off[i + 1]].copy()))
+    assert [k for k, _ in got] == list(exp["keys"])
+    np.testing.assert_array_equal(got[0][1], exp["m0"])                              # FM: bit exact
+    np.testing.assert_array_equal(got[1][1], exp["m1"].astype(np.float32))           # DM: rounded to float32
+    np.testing.assert_allclose(got[2][1], exp["m2"], rtol=0, atol=9.6e-7)            # CM: see test above
+    py = [m for _, m in kaldi_io.read_mat_ark(os.path.join(GOLD, "feats.ark"))]
+    np.testing.assert_array_equal(got[2][1], py[2])                                  # identical to the Python decoder
+
+
+def test_native_reader_batching_skip_and_pipe(native, tmp_path):
+    rs = np.random.RandomState(1)
+    lens = [30, 10, 200, 25, 24, 999, 50, 61]
+    mats = [rs.standard_normal((t, 5)).astype(np.float32) for t in lens]
+    path = str(tmp_path / "f.ark")
+    with open(path, "wb") as f:
+        for i, m in enumerate(mats):
+            kaldi_io.write_mat(f, m, key="k%d" % i)
+    for spec in (path, "ark:" + path, "ark:cat %s |" % path):
+        r = native.ArkBatchReader(spec, batch_frames=230, min_frames=25)
+        batches = list((k, o.copy(), f.copy()) for k, o, f in r)
+        assert r.skipped == 2                                                        # T=10 and T=24 (extract.py:65-67)
+        keys = [k for b in batches for k in b[0]]
+        assert keys == ["k0", "k2", "k3", "k5", "k6", "k7"]                          # input order
+        assert [len(b[0]) for b in batches] == [2, 2, 2]                             # stop once >= 230 frames
+        for ks, off, feats in batches:
+            for i, k in enumerate(ks):
+                np.testing.assert_array_equal(feats[off[i]:off[i + 1]], mats[int(k[1:])])
+        r.close()
+
+
+def test_native_reader_errors(native, tmp_path):
+    p = tmp_path / "bad.ark"
+    p.write_bytes(b"key \0BFM \x04\x05\0\0\0\x04\x02\0\0\0abc")                     # truncated payload
+    with pytest.raises(IOError):
+        list(native.ArkBatchReader(str(p)))
+    p.write_bytes(b"key \0BXX \x04\x05\0\0\0")
+    with pytest.raises(IOError):
+        list(native.ArkBatchReader(str(p)))
+    p.write_bytes(b"")
+    assert list(native.ArkBatchReader(str(p))) == []
+    with pytest.raises(ValueError):
+        native.ArkBatchReader("feats.ark.gz")
+
+
+def test_native_format_vectors_is_byte_identical(native):
+    exp = np.load(os.path.join(GOLD, "vectors_expected.npz"))
+    with open(os.path.join(GOLD, "vectors.ark"), "rb") as f:
+        ref = f.read()
+    first = native.format_vectors([str(exp["keys"][0])], exp["v0"][None])
+    assert ref.startswith(first)                                                     # the float32 record of the fixture
+    rs = np.random.RandomState(0)
+    v = rs.standard_normal((7, 33)).astype(np.float32)
+    keys = ["spk%d-utt_%d" % (i, i * i) for i in range(7)]
+    buf = io.BytesIO()
+    for k, x in zip(keys, v):
+        kaldi_io.write_vec_flt(buf, x, key=k)
+    assert native.format_vectors(keys, v) == buf.getvalue()

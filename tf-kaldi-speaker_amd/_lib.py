@@ -23,7 +23,8 @@ XV_ACT_RELU, XV_ACT_LRELU, XV_ACT_PRELU = 0, 1, 2
 
 EXPORTS = ["xv_version", "xv_create", "xv_set_tensor", "xv_finalize", "xv_node_id", "xv_node_context",
            "xv_plan_create", "xv_plan_query", "xv_plan_destroy", "xv_forward", "xv_profile_begin", "xv_profile_end",
-           "xv_destroy", "xv_last_error"]
+           "xv_destroy", "xv_last_error",
+           "xv_ark_open", "xv_ark_next_batch", "xv_ark_skipped", "xv_ark_error", "xv_ark_close", "xv_ark_format_vectors"]
 
 
 class ModelDesc(C.Structure):
@@ -93,8 +94,19 @@ def load():
     lib.xv_profile_end.argtypes = [vp, C.POINTER(KernelTime), i32, C.POINTER(i32)]
     lib.xv_destroy.argtypes = [vp]
     lib.xv_destroy.restype = None
+    lib.xv_ark_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    lib.xv_ark_next_batch.argtypes = [vp, i64, i32, i32, vp, i64, vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
+    lib.xv_ark_skipped.argtypes = [vp]
+    lib.xv_ark_skipped.restype = i64
+    lib.xv_ark_error.argtypes = [vp]
+    lib.xv_ark_error.restype = C.c_char_p
+    lib.xv_ark_close.argtypes = [vp]
+    lib.xv_ark_close.restype = None
+    lib.xv_ark_format_vectors.argtypes = [vp, i32, vp, i32, i64, vp, i64]
+    lib.xv_ark_format_vectors.restype = i64
     for n in EXPORTS:
-        if n not in ("xv_version", "xv_last_error", "xv_plan_destroy", "xv_destroy"):
+        if n not in ("xv_version", "xv_last_error", "xv_plan_destroy", "xv_destroy", "xv_ark_skipped", "xv_ark_error",
+                     "xv_ark_close", "xv_ark_format_vectors"):
             getattr(lib, n).restype = i32
     _lib = lib
     return lib

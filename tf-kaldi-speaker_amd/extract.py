@@ -41,6 +41,8 @@ def build_parser():
     parser.add_argument("--batch-frames", type=int, default=76800,
                         help="Frames packed into one device batch (extension; 76800 = 256 utterances x 300 frames).")
     parser.add_argument("--precision", type=str, default="", help="f32 | bf16x3 (extension; default: library default)")
+    parser.add_argument("--python-reader", action="store_true",
+                        help="Parse the ark with the pure-Python reader instead of the native batch reader (extension).")
     parser.add_argument("model_dir", type=str, help="The model directory.")
     parser.add_argument("rspecifier", type=str, help="Kaldi feature rspecifier (or ark file).")
     parser.add_argument("wspecifier", type=str, help="Kaldi output wspecifier (or ark file).")
@@ -70,20 +72,74 @@ def combine_chunks(embeddings, lengths, normalize):
     return np.sum(embeddings * lengths, axis=0) / np.sum(lengths)
 
 
+def _batches(items, min_chunk_size, chunk_size, batch_frames, counters):
+    """Group the (key, matrix) stream into device batches: yields (pieces, pending) where `pieces` is
+    the list of feature matrices to embed and `pending` = [(key, piece indices, chunk lengths | None)]."""
+    pending, pieces, frames = [], [], 0
+    for key, feature in items:
+        t = feature.shape[0]
+        if t < min_chunk_size:
+            log.info("[INFO] Key %s length too short, %d < %d, skip.", key, t, min_chunk_size)
+            counters["skipped"] += 1
+            continue
+        if t > chunk_size:
+            parts = split_chunks(t, chunk_size)
+            log.info("[INFO] Key %s length %d > %d, split to %d segments.", key, t, chunk_size, len(parts))
+            idx = []
+            for start, length in parts:
+                idx.append(len(pieces))
+                pieces.append(feature[start:start + length])
+            pending.append((key, idx, [p[1] for p in parts]))
+        else:
+            log.info("[INFO] Key %s length %d.", key, t)
+            pending.append((key, [len(pieces)], None))
+            pieces.append(feature)
+        frames += t
+        if frames >= batch_frames:
+            yield pieces, pending
+            pending, pieces, frames = [], [], 0
+    if pending:
+        yield pieces, pending
+
+
 def extract_stream(embed_fn, items, write_fn, min_chunk_size=25, chunk_size=10000, normalize=False,
-                   batch_frames=76800):
+                   batch_frames=76800, prefetch=2):
     """Core loop.  `items` yields (key, [T,d] matrix); `embed_fn(list of [T_i,d])` returns an
     [n,E] array; `write_fn(key, vector)` is called once per kept utterance, in input order.
+    With prefetch > 0 a producer thread parses the ark and groups the next batches while the caller's
+    thread embeds and writes the current one (ark parsing, device work and output overlap).
     Returns (#written, #skipped)."""
-    pending = []          # (key, [(piece_index...)], lengths or None)
-    pieces = []           # feature pieces of the current batch
-    frames = 0
-    done = skipped = 0
+    counters = {"skipped": 0}
+    gen = _batches(items, min_chunk_size, chunk_size, batch_frames, counters)
+    if prefetch > 0:
+        import queue
+        import threading
+        q = queue.Queue(maxsize=prefetch)
+        done_marker = object()
 
-    def flush():
-        nonlocal pieces, pending, frames, done
-        if not pending:
-            return
+        def producer():
+            try:
+                for b in gen:
+                    q.put(b)
+                q.put(done_marker)
+            except BaseException as e:          # surface parser errors in the consumer thread
+                q.put(e)
+
+        threading.Thread(target=producer, daemon=True).start()
+
+        def batches():
+            while True:
+                b = q.get()
+                if b is done_marker:
+                    return
+                if isinstance(b, BaseException):
+                    raise b
+                yield b
+        source = batches()
+    else:
+        source = gen
+    done = 0
+    for pieces, pending in source:
         emb = np.asarray(embed_fn(pieces))
         for key, idx, lengths in pending:
             if lengths is None:
@@ -94,30 +150,62 @@ def extract_stream(embed_fn, items, write_fn, min_chunk_size=25, chunk_size=1000
                 e = e / np.sqrt(np.sum(np.square(e)))                      # extract.py:91-92
             write_fn(key, np.asarray(e, dtype=np.float32))
             done += 1
-        pieces, pending, frames = [], [], 0
+    return done, counters["skipped"]
 
-    for key, feature in items:
-        t = feature.shape[0]
-        if t < min_chunk_size:
-            log.info("[INFO] Key %s length too short, %d < %d, skip." % (key, t, min_chunk_size))
-            skipped += 1
+
+def run_native(trainer, rspecifier, fp_out, min_chunk_size, chunk_size, normalize, batch_frames):
+    """Fast path of the driver: the native batch reader (csrc/ark_io.cpp) parses ark records straight into
+    pinned staging buffers on a background thread (outside the GIL) while this thread runs the device and
+    writes the previous batch; vectors are formatted per batch.  Batches containing an utterance longer
+    than chunk_size go through the generic chunking path on views of the same buffer."""
+    import queue
+    import threading
+    import torch
+    from . import native_ark
+    cap = (batch_frames + 65536) * 64
+    pins = [torch.empty(cap, dtype=torch.float32, pin_memory=True) for _ in range(3)]
+    reader = native_ark.ArkBatchReader(rspecifier, batch_frames=batch_frames, min_frames=min_chunk_size,
+                                       buffers=[p.numpy() for p in pins])
+    q = queue.Queue(maxsize=1)            # 3 buffers: one being filled, one queued, one in use
+    end = object()
+
+    def producer():
+        try:
+            for b in reader:
+                q.put(b)
+            q.put(end)
+        except BaseException as e:
+            q.put(e)
+
+    threading.Thread(target=producer, daemon=True).start()
+    done = 0
+    dev_index = trainer._device_index
+    while True:
+        b = q.get()
+        if b is end:
+            break
+        if isinstance(b, BaseException):
+            raise b
+        keys, offsets, feats = b
+        lens = np.diff(offsets)
+        if lens.max() > chunk_size:                     # rare: chunk / weight / average on views
+            items = [(k, feats[offsets[i]:offsets[i + 1]]) for i, k in enumerate(keys)]
+            out = []
+            extract_stream(trainer.predict_list, iter(items), lambda k, v: out.append((k, v)), min_chunk_size,
+                           chunk_size, normalize, batch_frames, prefetch=0)
+            fp_out.write(native_ark.format_vectors([k for k, _ in out], np.stack([v for _, v in out])))
+            done += len(out)
             continue
-        if t > chunk_size:
-            parts = split_chunks(t, chunk_size)
-            log.info("[INFO] Key %s length %d > %d, split to %d segments." % (key, t, chunk_size, len(parts)))
-            idx = []
-            for start, length in parts:
-                idx.append(len(pieces))
-                pieces.append(feature[start:start + length])
-            pending.append((key, idx, [p[1] for p in parts]))
-        else:
-            log.info("[INFO] Key %s length %d." % (key, t))
-            pending.append((key, [len(pieces)], None))
-            pieces.append(feature)
-        frames += t
-        if frames >= batch_frames:
-            flush()
-    flush()
+        host = torch.from_numpy(feats)                  # view of the pinned staging buffer
+        with torch.cuda.device(dev_index):
+            dev = host.to("cuda:%d" % dev_index, non_blocking=True)
+            emb = trainer.predict_packed(dev, offsets).cpu().numpy()
+        if normalize:
+            emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
+        fp_out.write(native_ark.format_vectors(keys, emb))
+        done += len(keys)
+    skipped = reader.skipped
+    reader.close()
     return done, skipped
 
 
@@ -144,11 +232,16 @@ def main(argv=None):
         sys.exit("The rspecifier must be ark or input pipe")
 
     fp_out = open_or_fd(args.wspecifier, "wb")
-    done, skipped = extract_stream(
-        trainer.predict_list, read_mat_ark(args.rspecifier),
-        lambda key, vec: write_vec_flt(fp_out, vec, key=key),
-        min_chunk_size=args.min_chunk_size, chunk_size=args.chunk_size, normalize=args.normalize,
-        batch_frames=args.batch_frames)
+    plain = args.rspecifier.split(":", 1)[-1].strip()
+    if not args.python_reader and not plain.endswith(".gz"):
+        done, skipped = run_native(trainer, args.rspecifier, fp_out, args.min_chunk_size, args.chunk_size,
+                                   args.normalize, args.batch_frames)
+    else:
+        done, skipped = extract_stream(
+            trainer.predict_list, read_mat_ark(args.rspecifier),
+            lambda key, vec: write_vec_flt(fp_out, vec, key=key),
+            min_chunk_size=args.min_chunk_size, chunk_size=args.chunk_size, normalize=args.normalize,
+            batch_frames=args.batch_frames)
     fp_out.close()
     proc = getattr(fp_out, "_xv_proc", None)
     if proc is not None:

@@ -70,6 +70,7 @@ class Trainer(object):
         self._ws = None
         self._step = None
         self._torch = None
+        self._pinned = None
 
     # ------------------------------------------------------------------ graph build
     def build(self, mode, noupdate_var_list=None):
@@ -356,13 +357,22 @@ class Trainer(object):
         d = int(utterances[0].shape[1])
         if d < self.dim:
             raise ValueError("features have %d columns, the network needs %d" % (d, self.dim))
-        host = np.concatenate([np.asarray(u, dtype=np.float32) for u in utterances], axis=0)
         offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        total = int(offsets[-1])
         with torch.cuda.device(self._device_index):
-            dev = torch.from_numpy(np.ascontiguousarray(host)).to("cuda:%d" % self._device_index)
+            # pack straight into a reusable pinned staging buffer (one copy), then one async H2D
+            pin = self._pinned
+            if pin is None or pin.shape[0] < total or pin.shape[1] != d:
+                pin = self._pinned = torch.empty((max(total, 4096), d), dtype=torch.float32, pin_memory=True)
+            stage = pin.numpy()
+            pos = 0
+            for u, t in zip(utterances, lens):
+                stage[pos:pos + t] = u
+                pos += t
+            dev = pin[:total].to("cuda:%d" % self._device_index, non_blocking=True)
             out = self.predict_packed(dev, offsets, node)
             _, info = self._plan(offsets, node)
-            emb = out.cpu().numpy()
+            emb = out.cpu().numpy()                     # synchronises: the staging buffer is free again
         if node == "attention_weights" or not info.frame_level:
             return emb
         ctx = (int(offsets[-1]) - emb.shape[0]) // len(lens)
@@ -382,6 +392,7 @@ class Trainer(object):
                 self._lib.xv_destroy(self._h)
                 self._h = None
         self._ws = None
+        self._pinned = None
         self.is_loaded = False
 
     def close(self):
