@@ -191,10 +191,22 @@ __global__ __launch_bounds__(WS ? 384 : 256, WS ? 3 : 2) void gemm_bf16x3_dma_ke
     __builtin_amdgcn_global_load_lds((gptr_t)(Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16),
                                      (lptr_t)(As + buf * DA_BYTES + g * 1024), 16, 0, 0);
   };
-  auto dma_b = [&](int kb, int buf, int g) {
-    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
-    __builtin_amdgcn_global_load_lds((gptr_t)(Bg + (int64_t)(8 * g) * b_row_bytes + (int64_t)kb * 128 + c * 16),
-                                     (lptr_t)(Bs + buf * DB_BYTES + g * 1024), 16, 0, 0);
+  // weight tile: wave `wv` of NL owns 16/NL CONSECUTIVE 1-KB groups, addressed with ONE M0 value plus the
+  // instruction's immediate offset (which the hardware adds to both the LDS and the global address, hence
+  // the "- Q * 1024" on the source pointer)
+  auto dma_b_all = [&](int kb, int buf, int wv) {
+    constexpr int GP = 16 / NL;                        // groups per wave (4, or 8 for the 2-loader variant)
+    char* lbase = Bs + buf * DB_BYTES + wv * GP * 1024;
+    const char* gbase = Bg + (int64_t)(8 * GP * wv) * b_row_bytes + (int64_t)kb * 128;
+#define XV_DMA_B(Q)                                                                                              \
+    if (Q < GP) {                                                                                                \
+      const int c = lpc ^ ((4 * (GP * wv + Q) + (lrow >> 1)) & 7);                                               \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gbase + (int64_t)(8 * Q) * b_row_bytes + c * 16 - Q * 1024),   \
+                                       (lptr_t)lbase, 16, Q * 1024, 0);                                          \
+    }
+    XV_DMA_B(0) XV_DMA_B(1) XV_DMA_B(2) XV_DMA_B(3)
+    if (GP > 4) { XV_DMA_B(4) XV_DMA_B(5) XV_DMA_B(6) XV_DMA_B(7) }
+#undef XV_DMA_B
   };
 
   f32x16 acc[2][2];
@@ -211,8 +223,7 @@ __global__ __launch_bounds__(WS ? 384 : 256, WS ? 3 : 2) void gemm_bf16x3_dma_ke
   int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : 128;   // K-block offset of slab cb + 1
   int blk_next = (kbt == 1 && p.a_pitch) ? 0 : 1;                  // its block index inside the tap
   if (loads) {
-#pragma unroll
-    for (int q = 0; q < 16 / NL; ++q) dma_b(0, 0, wave + NL * q);
+    dma_b_all(0, 0, wave);
   }
   __syncthreads();
 
@@ -232,8 +243,7 @@ __global__ __launch_bounds__(WS ? 384 : 256, WS ? 3 : 2) void gemm_bf16x3_dma_ke
     if (j_next == w) { j_next = 0; cb_next = cb + 1; }
     if (loads && s + 1 < nsteps && !(diag & 4)) {   // diag bit2: no weight DMA in the loop (timing only)
       const int kb = (diag & 32) ? 0 : j_next * ncb + cb_next;   // diag bit5: always the same (L2-hot) source tile
-#pragma unroll
-      for (int q = 0; q < 16 / NL; ++q) dma_b(kb, (s + 1) & 1, wave + NL * q);
+      dma_b_all(kb, (s + 1) & 1, wave);
     }
     if (loads && cb + 1 < ncb && !(diag & 8)) {     // diag bit3: no slab DMA in the loop (timing only)
       const int gend = min((j + 1) * gps, ngroups);
