@@ -6,9 +6,9 @@ model/trainer.py:148,277-295):
     <model_dir>/nnet/checkpoint      TF-style state file: model_checkpoint_path: "model-<step>"
     <model_dir>/nnet/model-<step>.npz   name -> float32 array, keyed by TF variable name
 
-The reference restores a TF checkpoint-V2 bundle through tf.train.Saver; reading that
-format without TensorFlow is SURVEY.md 8(f) rank 2 (next).  Until then the weight
-container is an .npz with the same variable names, written by `save_model`.
+Weights are either an .npz with the TF variable names as keys (written by `save_model`) or the
+TensorFlow checkpoint-V2 bundle itself (`model-<step>.index` + `.data-*`), parsed without
+TensorFlow by tf_checkpoint.py (unpinned: no real checkpoint available).
 """
 import json
 import os
@@ -51,13 +51,25 @@ def load_weights(nnet_dir):
     if not name:
         return None, None
     path = os.path.join(nnet_dir, name + ".npz")
-    if not os.path.isfile(path):
-        if os.path.isfile(os.path.join(nnet_dir, name + ".index")):
-            raise NotImplementedError(
-                "%s is a TensorFlow checkpoint-V2 bundle; convert it to %s.npz (variable name -> array). "
-                "A TF-free bundle reader is not part of this round." % (name, name))
-        return None, None
     step = int(next(re.finditer(r"(\d+)(?!.*\d)", name)).group(0))
+    if not os.path.isfile(path):
+        prefix = os.path.join(nnet_dir, name)
+        if os.path.isfile(prefix + ".index"):
+            # a TensorFlow checkpoint-V2 bundle (what Saver.restore reads, model/trainer.py:290): parsed
+            # without TensorFlow; optimizer slots / the loss layer are dropped later by name
+            from . import tf_checkpoint
+            weights = tf_checkpoint.read_bundle(prefix, name_filter=_graph_variable)
+            return {k: v.astype(np.float32) for k, v in weights.items()}, step
+        return None, None
     with np.load(path, allow_pickle=False) as z:
         weights = {k: z[k] for k in z.files}
     return weights, step
+
+
+def _graph_variable(name):
+    """Variables of the predict graph live under the network scope; skip optimizer slots
+    (".../Momentum", ".../Adam*"), the global step and the loss layer ("softmax/...")."""
+    if not name.startswith(("tdnn/", "etdnn/", "resnet_18/")):
+        return False
+    leaf = name.rsplit("/", 1)[-1]
+    return leaf in ("kernel", "bias", "gamma", "beta", "moving_mean", "moving_variance", "alpha", "query")
