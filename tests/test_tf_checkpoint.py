@@ -60,8 +60,12 @@ def test_bad_index_files(tmp_path):
     prefix = str(tmp_path / "c")
     tf_checkpoint.write_bundle(prefix, {"tdnn/x/kernel": np.ones((2, 2), np.float32)})
     raw = bytearray(open(prefix + ".index", "rb").read())
-    first_block_len = raw.index(b"\\x00\\x00\\x00\\x00\\x00", 8)          # trailer of the first data block
-    raw[first_block_len] = 1                                              # mark it snappy
+    footer = bytes(raw[-48:])
+    _, _, pos = tf_checkpoint._block_handle(footer, 0)
+    ioff, isize, _ = tf_checkpoint._block_handle(footer, pos)
+    _, handle = next(tf_checkpoint._read_block(bytes(raw), ioff, isize))
+    boff, bsize, _ = tf_checkpoint._block_handle(handle, 0)
+    raw[boff + bsize] = 1                                                 # compression byte of the first data block: snappy
     open(prefix + ".index", "wb").write(bytes(raw))
     with pytest.raises(tf_checkpoint.CheckpointFormatError):
         tf_checkpoint.read_bundle(prefix)
