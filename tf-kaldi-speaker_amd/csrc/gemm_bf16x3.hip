@@ -140,28 +140,17 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 }  // namespace
 
-// WS = warp-specialised form: 384 threads, waves 0-3 are CONSUMERS (ds_read + MFMA + epilogue only)
-// and waves 4-5 LOADERS that only issue the DMA of the next step and then wait at the barrier
-// (two loaders: 3 waves per SIMD with two workgroups per CU keeps a 168-VGPR budget).  An
-// LDS-DMA piece costs the issuing wave 60-185 issue cycles (MI355X_MICROARCH.md), ~4.6 pieces per
-// wave per step next to a 768-cycle MFMA phase; the idea was to let the consumer stream run in the
-// "ds_read + MFMA only" regime of the ablation.  MEASURED: 2.3x slower (L3 1.59 vs 0.69 ms) -- one
-// wave's stream of 9 LDS-DMA pieces takes ~3 us to land, so the pieces must stay spread over all
-// waves.  Kept only as an A/B variant (XVEC_GEMM_SCHED=2); WS = false is the product path.
-template <bool WS>
-__global__ __launch_bounds__(WS ? 384 : 256, WS ? 3 : 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int nMt, int nNt, int w,
-                                                                                     int diag) {
+// (A warp-specialised form -- consumer waves + dedicated DMA loader waves -- was measured at 2x SLOWER and
+// removed: profiles/README.md.)
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int nMt, int nNt, int w, int diag) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   char* As = smem3;                      // [2][DA_ROWS][128]
   char* Bs = smem3 + 2 * DA_BYTES;       // [2][BN][128]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = WS && wave_id >= 4;          // wave-uniform role
-  const bool loads = !WS || loader, computes = !WS || !loader;
-  const int wave = wave_id & 3;                    // index inside the role (tile quadrant / DMA share)
-  constexpr int NL = WS ? 2 : 4;                   // waves that share the DMA work
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NL = 4;                            // every wave issues its share of the DMA pieces
   const int wm = wave >> 1, wn = wave & 1;
   const int r32 = lane & 31, h = lane >> 5;
 
@@ -195,7 +184,7 @@ __global__ __launch_bounds__(WS ? 384 : 256, WS ? 3 : 2) void gemm_bf16x3_dma_ke
   // instruction's immediate offset (which the hardware adds to both the LDS and the global address, hence
   // the "- Q * 1024" on the source pointer)
   auto dma_b_all = [&](int kb, int buf, int wv) {
-    constexpr int GP = 16 / NL;                        // groups per wave (4, or 8 for the 2-loader variant)
+    constexpr int GP = 16 / NL;                        // groups per wave
     char* lbase = Bs + buf * DB_BYTES + wv * GP * 1024;
     const char* gbase = Bg + (int64_t)(8 * GP * wv) * b_row_bytes + (int64_t)kb * 128;
 #define XV_DMA_B(Q)                                                                                              \
@@ -205,7 +194,6 @@ __global__ __launch_bounds__(WS ? 384 : 256, WS ? 3 : 2) void gemm_bf16x3_dma_ke
                                        (lptr_t)lbase, 16, Q * 1024, 0);                                          \
     }
     XV_DMA_B(0) XV_DMA_B(1) XV_DMA_B(2) XV_DMA_B(3)
-    if (GP > 4) { XV_DMA_B(4) XV_DMA_B(5) XV_DMA_B(6) XV_DMA_B(7) }
 #undef XV_DMA_B
   };
 
@@ -218,13 +206,10 @@ __global__ __launch_bounds__(WS ? 384 : 256, WS ? 3 : 2) void gemm_bf16x3_dma_ke
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // prologue: whole slab 0 and the weight tile of step 0
-  if (loads)
-    for (int g = wave; g < ngroups; g += NL) dma_a(0, 0, g);
+  for (int g = wave; g < ngroups; g += NL) dma_a(0, 0, g);
   int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : 128;   // K-block offset of slab cb + 1
   int blk_next = (kbt == 1 && p.a_pitch) ? 0 : 1;                  // its block index inside the tap
-  if (loads) {
-    dma_b_all(0, 0, wave);
-  }
+  dma_b_all(0, 0, wave);
   __syncthreads();
 
   // B fragment offsets (row fixed per lane): chunk c = plane*4 + ks*2 + h
@@ -241,16 +226,15 @@ __global__ __launch_bounds__(WS ? 384 : 256, WS ? 3 : 2) void gemm_bf16x3_dma_ke
   for (int s = 0; s < nsteps; ++s) {
     int cb_next = cb, j_next = j + 1;
     if (j_next == w) { j_next = 0; cb_next = cb + 1; }
-    if (loads && s + 1 < nsteps && !(diag & 4)) {   // diag bit2: no weight DMA in the loop (timing only)
+    if (s + 1 < nsteps && !(diag & 4)) {   // diag bit2: no weight DMA in the loop (timing only)
       const int kb = (diag & 32) ? 0 : j_next * ncb + cb_next;   // diag bit5: always the same (L2-hot) source tile
       dma_b_all(kb, (s + 1) & 1, wave);
     }
-    if (loads && cb + 1 < ncb && !(diag & 8)) {     // diag bit3: no slab DMA in the loop (timing only)
+    if (cb + 1 < ncb && !(diag & 8)) {     // diag bit3: no slab DMA in the loop (timing only)
       const int gend = min((j + 1) * gps, ngroups);
       for (int g = j * gps + wave; g < gend; g += NL) dma_a((diag & 32) ? 0 : koff_next, (cb + 1) & 1, g);
     }
 
-    if (computes) {
     const char* ab = As + (cb & 1) * DA_BYTES;
     const char* bb = Bs + (s & 1) * DB_BYTES;
     int aoff[2], aswz[2];
@@ -281,7 +265,6 @@ __global__ __launch_bounds__(WS ? 384 : 256, WS ? 3 : 2) void gemm_bf16x3_dma_ke
           acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[ks][nj], ah[ks][mi], acc[nj][mi], 0, 0, 0);
           acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[ks][nj], ah[ks][mi], acc[nj][mi], 0, 0, 0);
         }
-    }
     if (!(diag & 16)) __syncthreads();     // diag bit4: no barrier (timing only, racy)
     if (cb_next != cb) {                 // advance the A K-block offset with the slab index
       if (++blk_next == kbt) {
@@ -295,7 +278,6 @@ __global__ __launch_bounds__(WS ? 384 : 256, WS ? 3 : 2) void gemm_bf16x3_dma_ke
     j = j_next;
   }
 
-  if (loader) return;     // loaders are done; s_barrier waits only on the surviving waves of the workgroup
   if (diag & 2) {       // diag bit1: skip the epilogue stores (keep the accumulators live)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -470,7 +452,7 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   static int force = -1;        // XVEC_GEMM_TILE=128 register-staged | 1 DMA 128x128 | 256 pipelined 256x128; 0 = by size
   static bool attr_set = false;
-  static int sched = 0, diag = 0;   // XVEC_GEMM_SCHED=2: warp-specialised variant; XVEC_GEMM_DIAG: timing-only switches
+  static int diag = 0;              // XVEC_GEMM_DIAG: timing-only ablation switches (outputs invalid)
   const size_t smem128 = (size_t)4 * TILE_B;
   const size_t smemdma = (size_t)2 * DA_BYTES + 2 * DB_BYTES;
   const size_t smempipe = (size_t)3 * PA_BYTES + 3 * PB_BYTES;
@@ -480,16 +462,12 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
     if (r != hipSuccess) return r;
-    for (const void* f : {reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<false>),
-                          reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel<true>)}) {
-      r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemdma);
-      if (r != hipSuccess) return r;
-    }
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemdma);
+    if (r != hipSuccess) return r;
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_pipe_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smempipe);
     if (r != hipSuccess) return r;
-    const char* e2 = getenv("XVEC_GEMM_SCHED");
-    sched = e2 ? atoi(e2) : 0;
     const char* e3 = getenv("XVEC_GEMM_DIAG");
     diag = e3 ? atoi(e3) : 0;
     attr_set = true;
@@ -503,10 +481,7 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
   }
   if (force != 128 && taps_ok) {
     const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
-    if (sched == 2)     // XVEC_GEMM_SCHED=2: warp-specialised A/B variant (measured 2.3x SLOWER: profiles/README.md)
-      hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<true>, dim3(nMt * nNt), dim3(384), smemdma, s, a, nMt, nNt, w, diag);
-    else
-      hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<false>, dim3(nMt * nNt), dim3(256), smemdma, s, a, nMt, nNt, w, diag);
+    hipLaunchKernelGGL(gemm_bf16x3_dma_kernel, dim3(nMt * nNt), dim3(256), smemdma, s, a, nMt, nNt, w, diag);
     return hipGetLastError();
   }
   const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
