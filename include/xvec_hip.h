@@ -172,6 +172,16 @@ typedef struct {
 int xv_profile_begin(xv_handle* h, int max_events);
 int xv_profile_end(xv_handle* h, xv_kernel_time* entries, int max_entries, int* n_forwards);
 
+/* ---- feature front-end on the GPU (csrc/frontend.hip): what the reference runs as Kaldi binaries in
+ * front of extract.py (egs/voxceleb/v1/nnet/run_extract_embeddings.sh:47),
+ *   apply-cmvn-sliding --norm-vars=false --center=true --cmn-window=W  |  select-voiced-frames.
+ * feats_dev [in_frames, ld] (first `dim` columns), frame_offsets_dev [B+1] (device), src_rows_dev
+ * [out_rows]: input row of every kept frame (ascending inside an utterance; the host derives it from the
+ * VAD decisions), scratch_dev: (in_frames + B) * dim doubles.  cmn_window 0 = selection only.  Writes out_dev [out_rows, dim] float32. */
+int xv_frontend_cmn_select(int device, const float* feats_dev, int ld, int dim, const int32_t* frame_offsets_dev,
+                           int batch, const int32_t* src_rows_dev, int64_t out_rows, int cmn_window, int center,
+                           int min_window, double* scratch_dev, float* out_dev, void* stream);
+
 /* ---- host-side ark I/O (csrc/ark_io.cpp; no HIP calls, usable without a GPU) ---------------------
  * Batch counterpart of dataset/kaldi_io.py read_mat_ark (:974-994, records per _read_mat_binary
  * :1014-1031 / _read_compressed_mat :1071-1115) and write_vec_flt (:915-946): the extraction driver

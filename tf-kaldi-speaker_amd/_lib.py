@@ -24,6 +24,7 @@ XV_ACT_RELU, XV_ACT_LRELU, XV_ACT_PRELU = 0, 1, 2
 EXPORTS = ["xv_version", "xv_create", "xv_set_tensor", "xv_finalize", "xv_node_id", "xv_node_context",
            "xv_plan_create", "xv_plan_query", "xv_plan_destroy", "xv_forward", "xv_profile_begin", "xv_profile_end",
            "xv_destroy", "xv_last_error",
+           "xv_frontend_cmn_select",
            "xv_ark_open", "xv_ark_next_batch", "xv_ark_skipped", "xv_ark_error", "xv_ark_close", "xv_ark_format_vectors"]
 
 
@@ -94,6 +95,7 @@ def load():
     lib.xv_profile_end.argtypes = [vp, C.POINTER(KernelTime), i32, C.POINTER(i32)]
     lib.xv_destroy.argtypes = [vp]
     lib.xv_destroy.restype = None
+    lib.xv_frontend_cmn_select.argtypes = [i32, vp, i32, i32, vp, i32, vp, i64, i32, i32, i32, vp, vp, vp]
     lib.xv_ark_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
     lib.xv_ark_next_batch.argtypes = [vp, i64, i32, i32, vp, i64, vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
     lib.xv_ark_skipped.argtypes = [vp]

@@ -120,6 +120,11 @@ hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0,
 hipError_t launch_grid_unpad_n(const float* grid, const int32_t* off0, int B, int F, int C, int64_t frames, float* out,
                                hipStream_t s);
 
+// sliding-window CMN + voiced-frame selection (csrc/frontend.hip); prefix: double [(frames + B) * dim] scratch
+hipError_t launch_cmn_select(const float* x, int64_t ld, int dim, const int32_t* off, int B, double* prefix,
+                             const int32_t* src, int64_t out_rows, int window, int center, int min_window, float* out,
+                             hipStream_t s);
+
 // attention scores (model/pooling.py:189-194): score[r, h] = scale * sum_d key[r, h*dk_h + d] * q[h, d]
 // (split_key) or sum_d key[r, d] * q[h, d] (no split; dk_h == dk).
 hipError_t launch_att_scores(const float* key, int64_t ldk, int64_t rows, const float* query, int H,

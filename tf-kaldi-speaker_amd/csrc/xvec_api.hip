@@ -1288,6 +1288,21 @@ int xv_profile_end(xv_handle* h, xv_kernel_time* entries, int max_entries, int* 
   return n;
 }
 
+int xv_frontend_cmn_select(int device, const float* feats_dev, int ld, int dim, const int32_t* frame_offsets_dev,
+                           int batch, const int32_t* src_rows_dev, int64_t out_rows, int cmn_window, int center,
+                           int min_window, double* scratch_dev, float* out_dev, void* stream) {
+  if (!feats_dev || !frame_offsets_dev || !src_rows_dev || !scratch_dev || !out_dev)
+    return fail(nullptr, XV_ERR_INVALID, "xv_frontend_cmn_select: null pointer");
+  if (dim < 1 || dim > 1024 || ld < dim || batch < 1 || out_rows < 0 || cmn_window < 0)
+    return fail(nullptr, XV_ERR_INVALID, "xv_frontend_cmn_select: bad dimensions");
+  DeviceGuard g(device);
+  if (!g.ok) return fail(nullptr, XV_ERR_HIP, "cannot select HIP device %d", device);
+  const hipError_t e = launch_cmn_select(feats_dev, ld, dim, frame_offsets_dev, batch, scratch_dev, src_rows_dev, out_rows,
+                                         cmn_window, center, min_window, out_dev, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(nullptr, XV_ERR_HIP, "cmn_select launch failed: %s", hipGetErrorString(e));
+  return XV_OK;
+}
+
 void xv_destroy(xv_handle* h) {
   if (!h) return;
   {

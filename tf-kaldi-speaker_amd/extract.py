@@ -43,6 +43,13 @@ def build_parser():
     parser.add_argument("--precision", type=str, default="", help="f32 | bf16x3 (extension; default: library default)")
     parser.add_argument("--python-reader", action="store_true",
                         help="Parse the ark with the pure-Python reader instead of the native batch reader (extension).")
+    parser.add_argument("--cmn-window", type=int, default=0,
+                        help="Apply centred sliding-window CMN of this many frames on the GPU before the network "
+                             "(extension; replaces `apply-cmvn-sliding --norm-vars=false --center=true` of "
+                             "run_extract_embeddings.sh:47; 0 = features are already normalised).")
+    parser.add_argument("--vad-rspecifier", type=str, default="",
+                        help="Kaldi vector ark of per-frame VAD decisions, same key order as the features; voiced frames "
+                             "are selected on the GPU (extension; replaces `select-voiced-frames`).")
     parser.add_argument("model_dir", type=str, help="The model directory.")
     parser.add_argument("rspecifier", type=str, help="Kaldi feature rspecifier (or ark file).")
     parser.add_argument("wspecifier", type=str, help="Kaldi output wspecifier (or ark file).")
@@ -153,7 +160,22 @@ def extract_stream(embed_fn, items, write_fn, min_chunk_size=25, chunk_size=1000
     return done, counters["skipped"]
 
 
-def run_native(trainer, rspecifier, fp_out, min_chunk_size, chunk_size, normalize, batch_frames):
+def _vad_lookup(vad_rspecifier):
+    """Lock-step lookup in a VAD vector ark that is in the same key order as the features (Kaldi's `scp,s,cs`
+    contract of select-voiced-frames): returns f(key) -> vector, skipping VAD entries without features."""
+    from .kaldi_io import read_vec_flt_ark
+    it = iter(read_vec_flt_ark(vad_rspecifier))
+
+    def lookup(key):
+        for k, v in it:
+            if k == key:
+                return v
+        raise KeyError("no VAD decisions for utterance %s (VAD ark must be in feature order)" % key)
+    return lookup
+
+
+def run_native(trainer, rspecifier, fp_out, min_chunk_size, chunk_size, normalize, batch_frames, cmn_window=0,
+               vad_rspecifier=""):
     """Fast path of the driver: the native batch reader (csrc/ark_io.cpp) parses ark records straight into
     pinned staging buffers on a background thread (outside the GIL) while this thread runs the device and
     writes the previous batch; vectors are formatted per batch.  Batches containing an utterance longer
@@ -164,7 +186,10 @@ def run_native(trainer, rspecifier, fp_out, min_chunk_size, chunk_size, normaliz
     from . import native_ark
     cap = (batch_frames + 65536) * 64
     pins = [torch.empty(cap, dtype=torch.float32, pin_memory=True) for _ in range(3)]
-    reader = native_ark.ArkBatchReader(rspecifier, batch_frames=batch_frames, min_frames=min_chunk_size,
+    frontend = cmn_window > 0 or bool(vad_rspecifier)
+    vad_of = _vad_lookup(vad_rspecifier) if vad_rspecifier else None
+    # with the front-end on, the min-length rule applies to the lengths after frame selection
+    reader = native_ark.ArkBatchReader(rspecifier, batch_frames=batch_frames, min_frames=1 if frontend else min_chunk_size,
                                        buffers=[p.numpy() for p in pins])
     q = queue.Queue(maxsize=1)            # 3 buffers: one being filled, one queued, one in use
     end = object()
@@ -178,7 +203,7 @@ def run_native(trainer, rspecifier, fp_out, min_chunk_size, chunk_size, normaliz
             q.put(e)
 
     threading.Thread(target=producer, daemon=True).start()
-    done = 0
+    done = extra_skipped = 0
     dev_index = trainer._device_index
     while True:
         b = q.get()
@@ -187,6 +212,27 @@ def run_native(trainer, rspecifier, fp_out, min_chunk_size, chunk_size, normaliz
         if isinstance(b, BaseException):
             raise b
         keys, offsets, feats = b
+        if frontend:
+            from .frontend import cmn_select_packed
+            vads = [vad_of(k) for k in keys] if vad_of else None
+            with torch.cuda.device(dev_index):
+                raw = torch.from_numpy(feats).to("cuda:%d" % dev_index, non_blocking=True)
+                dev, offsets, kept = cmn_select_packed(raw, offsets, vads, cmn_window=cmn_window,
+                                                       min_frames=min_chunk_size)
+            extra_skipped += len(keys) - len(kept)
+            keys = [keys[i] for i in kept]
+            if not keys:
+                continue
+            if np.diff(offsets).max() > chunk_size:     # rare: finish on the host views of the processed batch
+                feats = dev.cpu().numpy()
+            else:
+                with torch.cuda.device(dev_index):
+                    emb = trainer.predict_packed(dev, offsets).cpu().numpy()
+                if normalize:
+                    emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
+                fp_out.write(native_ark.format_vectors(keys, emb))
+                done += len(keys)
+                continue
         lens = np.diff(offsets)
         if lens.max() > chunk_size:                     # rare: chunk / weight / average on views
             items = [(k, feats[offsets[i]:offsets[i + 1]]) for i, k in enumerate(keys)]
@@ -204,7 +250,7 @@ def run_native(trainer, rspecifier, fp_out, min_chunk_size, chunk_size, normaliz
             emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
         fp_out.write(native_ark.format_vectors(keys, emb))
         done += len(keys)
-    skipped = reader.skipped
+    skipped = reader.skipped + extra_skipped
     reader.close()
     return done, skipped
 
@@ -233,9 +279,12 @@ def main(argv=None):
 
     fp_out = open_or_fd(args.wspecifier, "wb")
     plain = args.rspecifier.split(":", 1)[-1].strip()
+    frontend = args.cmn_window > 0 or bool(args.vad_rspecifier)
+    if frontend and (args.python_reader or plain.endswith(".gz")):
+        sys.exit("--cmn-window / --vad-rspecifier need the native reader (plain ark or pipe input)")
     if not args.python_reader and not plain.endswith(".gz"):
         done, skipped = run_native(trainer, args.rspecifier, fp_out, args.min_chunk_size, args.chunk_size,
-                                   args.normalize, args.batch_frames)
+                                   args.normalize, args.batch_frames, args.cmn_window, args.vad_rspecifier)
     else:
         done, skipped = extract_stream(
             trainer.predict_list, read_mat_ark(args.rspecifier),
