@@ -132,6 +132,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs p, int nMt
 // tile and this step's share of the next slab, read 16 fragments, 24 MFMAs, __syncthreads()
 // (whose vmcnt(0) retires the DMA issued ~800 cycles earlier).
 namespace {
+#ifndef XV_WREG_LPG
+#define XV_WREG_LPG 1
+#endif
 constexpr int DROW = 128;                          // unpadded LDS row
 constexpr int DA_ROWS = 136;                       // 128 + (w-1 <= 7) halo rows, multiple of 8
 constexpr int DA_BYTES = DA_ROWS * DROW;
@@ -251,9 +254,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
       for (int i = 0; i < 2; ++i) {
         const int ch = ks * 2 + h, cl = 4 + ks * 2 + h;
         ah[ks][i] = *reinterpret_cast<const bf16x8*>(ab + aoff[i] + ((ch ^ aswz[i]) << 4));
-        al[ks][i] = *reinterpret_cast<const bf16x8*>(ab + aoff[i] + ((cl ^ aswz[i]) << 4));
         bh[ks][i] = *reinterpret_cast<const bf16x8*>(bb + boff[i] + ((ch ^ bswz[i]) << 4));
-        bl[ks][i] = *reinterpret_cast<const bf16x8*>(bb + boff[i] + ((cl ^ bswz[i]) << 4));
+        if (diag & 64) {                 // diag bit6: half the LDS fragment reads (timing only, wrong results)
+          al[ks][i] = ah[ks][i];
+          bl[ks][i] = bh[ks][i];
+        } else {
+          al[ks][i] = *reinterpret_cast<const bf16x8*>(ab + aoff[i] + ((cl ^ aswz[i]) << 4));
+          bl[ks][i] = *reinterpret_cast<const bf16x8*>(bb + boff[i] + ((cl ^ bswz[i]) << 4));
+        }
       }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -287,6 +295,183 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
   }
   // the final barrier of the K loop has retired every LDS read: reuse the tiles as store scratch
   store_wave_tile(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, smem3);
+}
+
+// ------------------------------------------------------------------------------------------
+// 128x128 "weights in registers" kernel: the activation slab is staged exactly as in the DMA kernel, but
+// the weight fragments never touch LDS -- every lane loads its own 16-byte MFMA fragments of the packed
+// weight rows straight from L2/L1 (global_load_dwordx4, one step ahead, double-buffered in VGPRs).
+//  * 85 % of the LDS-DMA pieces of the kernel above were weight tiles; they and their landing wait go;
+//  * the only LDS hazard left is the slab, so the workgroup barrier drops from one per K step to one per
+//    channel block (every w steps);
+//  * the waits on the weight loads are per-register vmcnt(N) counts placed by the compiler, not vmcnt(0).
+//  * NPS = slab DMA pieces per wave per step (1 when w >= 5: 4w slots cover the <= 17 groups; 4 otherwise),
+//    fully unrolled: a variable-trip DMA loop makes the compiler fall back to vmcnt(0) everywhere.
+//  * EROWS = frames per epilogue pass: 32 -> 8 KB of scratch per wave, the workgroup needs only the 34 KB of
+//    the slabs and THREE workgroups share a CU (12 waves; 2288 tiles / 768 slots = 2.98 rounds instead of
+//    4.47 on 512); 64 -> 64 KB, two workgroups (the fused-pooling layer).
+//  * MI = 32-frame MFMA tiles per wave along M (2 -> the 128-frame workgroup tile).  MI = 1 half-height tiles for
+//    the last partial round of a launch were tried and gave nothing: a per-workgroup trace (tools/gemm_trace.py)
+//    shows that a workgroup alone on a CU is bound by the load->use latency of its weight fragments
+//    (~1.16 us per K step), not by its MFMA work, so halving the work of the stragglers does not shorten them.
+template <int NPS, int EROWS, int MI>
+__device__ __forceinline__ void wreg_tile(const GemmArgs& p, int m0, int n0, int w, int diag, char* smem3) {
+  constexpr int BMk = 64 * MI;           // frames per workgroup tile
+  char* As = smem3;                      // [2][DA_ROWS][128]; the rest of the allocation is epilogue scratch
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+
+  const int ncb = (p.Kpad >> 5) / w;
+  const int nsteps = ncb * w;
+  const int ngroups = (BMk + w - 1 + 7) >> 3;
+  const int lrow = lane >> 3, lpc = lane & 7;
+  const int64_t a_row_bytes = (p.a_pitch ? p.a_pitch : p.ldsbx) * 4, b_row_bytes = (int64_t)p.Kpad * 4;
+  const int kbt = p.a_pitch ? (p.ktap >> 5) : (p.Kpad >> 5);
+  const int64_t tap_bytes = p.a_pitch ? p.tap_stride * 4 : 0;
+  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(m0 + lrow) * a_row_bytes;
+  // fragment-major weights: 32-row block nb, K block kb, c = plane*2 + ks -> 64 lanes x 16 B contiguous
+  const int64_t nkb4k = (int64_t)(p.Kpad >> 5) * 4096;
+  const char* Wg0 = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((n0 + wn * 64) >> 5) * nkb4k + lane * 16;
+  const char* Wg1 = Wg0 + nkb4k;
+
+  auto dma_a = [&](int64_t koff, int buf, int g) {
+    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
+    __builtin_amdgcn_global_load_lds((gptr_t)(Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16),
+                                     (lptr_t)(As + buf * DA_BYTES + g * 1024), 16, 0, 0);
+  };
+  // W[nj*4 + plane*2 + ks]
+  auto load_w = [&](bf16x8 (&W)[8], int kb) {
+    const char* q0 = Wg0 + (int64_t)kb * 4096;
+    const char* q1 = Wg1 + (int64_t)kb * 4096;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      W[c] = *reinterpret_cast<const bf16x8*>(q0 + c * 1024);
+      W[4 + c] = *reinterpret_cast<const bf16x8*>(q1 + c * 1024);
+    }
+  };
+
+  f32x16 acc[2][MI];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto stamp = [&](int i) {            // debug trace (build with -DXV_GEMM_TRACE, run with XVEC_TRACE_K): 100 MHz stamps
+#ifdef XV_GEMM_TRACE
+    if (p.trace && tid == 0) p.trace[(int64_t)blockIdx.x * 4 + i] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  };
+  stamp(0);
+  bf16x8 W0[8], W1[8];
+  load_w(W0, 0);
+  for (int g = wave; g < ngroups; g += 4) dma_a(0, 0, g);
+  int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : 128;
+  int blk_next = (kbt == 1 && p.a_pitch) ? 0 : 1;
+  __syncthreads();
+
+  stamp(1);
+  int cb = 0, j = 0;
+  auto step = [&](int s, bf16x8 (&Wc)[8], bf16x8 (&Wn)[8]) __attribute__((always_inline)) {
+    int cb_next = cb, j_next = j + 1;
+    if (j_next == w) { j_next = 0; cb_next = cb + 1; }
+    // Everything issued one step ago (this step's weights, slab pieces) must have landed; saying so HERE, before
+    // the new loads are issued, keeps the compiler from placing a vmcnt(0) after them (it cannot order
+    // LDS-DMA against register loads in the counter and would wait for the loads it has just issued).
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+    // Issue is UNCONDITIONAL (clamped duplicates instead of branches): the compiler's vmcnt(N) for the
+    // weight registers must hold on every path, and a path that skips the issue forces vmcnt(0).
+    // Issue order is written out by hand and pinned with sched_barrier: the 8 weight loads and the slab piece are
+    // spread between the MFMAs (one per 3 MFMAs), not issued as a burst -- a burst from all 8 waves of the CU
+    // queues up in the texture-address unit and the in-order waves stop feeding the matrix pipe meanwhile.
+    const int kbn = (s + 1 < nsteps && !(diag & 32)) ? j_next * ncb + cb_next : 0;
+    const char* q0 = Wg0 + (int64_t)kbn * 4096;
+    const char* q1 = Wg1 + (int64_t)kbn * 4096;
+    const char* ab = As + (cb & 1) * DA_BYTES;
+    int aoff[MI], aswz[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int ra = wm * (32 * MI) + mi * 32 + r32 + j;
+      aoff[mi] = ra * DROW;
+      aswz[mi] = (ra >> 1) & 7;
+    }
+    bf16x8 ah[2][MI], al[2][MI];         // [ks][mi]
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      ah[0][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + ((h ^ aswz[mi]) << 4));
+      al[0][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((4 + h) ^ aswz[mi]) << 4));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (!(diag & 4)) {
+        // XV_WREG_LPG weight loads per group: 1 = spread over the whole step, 2 / 4 = first half / quarter
+        constexpr int lpg = XV_WREG_LPG;
+#pragma unroll
+        for (int l = 0; l < lpg; ++l) {
+          const int gi = g * lpg + l;
+          if (gi < 8) Wn[gi] = *reinterpret_cast<const bf16x8*>((gi < 4 ? q0 : q1) + (gi & 3) * 1024);
+        }
+      }
+      if (g < 2 * MI) {                  // ks = 1 fragments trickle in behind the ks = 0 MFMAs
+        const int mi = g >> 1;
+        if (g & 1) al[1][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((6 + h) ^ aswz[mi]) << 4));
+        else       ah[1][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((2 + h) ^ aswz[mi]) << 4));
+      }
+#pragma unroll
+      for (int t = g * (12 * MI) / 8; t < (g + 1) * (12 * MI) / 8; ++t) {   // 3 (MI = 2) or 1-2 (MI = 1) MFMAs per group
+        const int ks = t / (6 * MI), rem = t % (6 * MI), mi = rem / 6, nj = (rem / 3) & 1, term = rem % 3;
+        const bf16x8 wh = Wc[nj * 4 + ks], wl = Wc[nj * 4 + 2 + ks];
+        if (term == 0) acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al[ks][mi], acc[nj][mi], 0, 0, 0);
+        if (term == 1) acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah[ks][mi], acc[nj][mi], 0, 0, 0);
+        if (term == 2) acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah[ks][mi], acc[nj][mi], 0, 0, 0);
+      }
+      if (g == 3 && !(diag & 8)) {       // slab piece(s) of the next channel block, mid-step
+        const int64_t ksrc = cb + 1 < ncb ? koff_next : 0;    // last block: harmless re-stage into the idle buffer
+#pragma unroll
+        for (int i = 0; i < NPS; ++i) dma_a(ksrc, (cb + 1) & 1, min((j * NPS + i) * 4 + wave, ngroups - 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (cb_next != cb) {                 // slab switch: the only LDS hand-over
+      if (!(diag & 16)) __syncthreads();
+      if (++blk_next == kbt) {
+        blk_next = 0;
+        koff_next += tap_bytes - (int64_t)(kbt - 1) * 128;
+      } else {
+        koff_next += 128;
+      }
+    }
+    cb = cb_next;
+    j = j_next;
+  };
+  for (int s = 0; s < nsteps; s += 2) {
+    step(s, W0, W1);
+    if (s + 1 < nsteps) step(s + 1, W1, W0);
+  }
+  if (diag & 2) {       // diag bit1: skip the epilogue stores (timing only)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) asm volatile("" ::"v"(acc[nj][mi]));
+    return;
+  }
+  stamp(2);
+  store_wave_tile<EROWS, MI>(p, acc, m0 + wm * (32 * MI), n0 + wn * 64, lane, wave, smem3);
+  stamp(3);
+}
+
+template <int NPS, int EROWS>
+__global__ __launch_bounds__(256, EROWS == 32 ? 3 : 2) void gemm_bf16x3_wreg_kernel(GemmArgs p, int nMt, int nNt, int w, int diag) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
+  const int mt = tile / nNt, nt = tile - mt * nNt;
+  wreg_tile<NPS, EROWS, 2>(p, mt * BM, nt * BN, w, diag, smem3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -448,14 +633,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_pipe_kernel(GemmArgs p, in
   store_wave_tile(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, smem3);
 }
 
-hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
-  if (a.M <= 0) return hipSuccess;
-  static int force = -1;        // XVEC_GEMM_TILE=128 register-staged | 1 DMA 128x128 | 256 pipelined 256x128; 0 = by size
+namespace {
+long long* g_trace = nullptr;      // debug trace buffer (device), kTraceWgs workgroups x 4 stamps
+int g_trace_wgs = 0;
+constexpr int kTraceWgs = 16384;
+}  // namespace
+
+hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
+  if (a_in.M <= 0) return hipSuccess;
+  GemmArgs a = a_in;
+  {
+    static int trace_k = -1;
+    if (trace_k < 0) { const char* e = getenv("XVEC_TRACE_K"); trace_k = e ? atoi(e) : 0; }
+    if (trace_k > 0 && a.K == trace_k) {
+      if (!g_trace && hipMalloc(&g_trace, sizeof(long long) * 4 * kTraceWgs) != hipSuccess) g_trace = nullptr;
+      const int wgs = ((a.M + BM - 1) / BM) * (a.Npad / BN);
+      if (g_trace && wgs <= kTraceWgs) { a.trace = g_trace; g_trace_wgs = wgs; }
+    }
+  }
+  static int force = -1;        // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA 128x128 | 256 pipelined 256x128; 0 = default (weights in registers)
   static bool attr_set = false;
   static int diag = 0;              // XVEC_GEMM_DIAG: timing-only ablation switches (outputs invalid)
   const size_t smem128 = (size_t)4 * TILE_B;
   const size_t smemdma = (size_t)2 * DA_BYTES + 2 * DB_BYTES;
   const size_t smempipe = (size_t)3 * PA_BYTES + 3 * PB_BYTES;
+  const size_t smemw32 = (size_t)2 * DA_BYTES, smemw64 = 65536;   // slabs (>= 4 x 8 KB scratch) | 4 x 16 KB scratch
   if (!attr_set) {
     const char* e = getenv("XVEC_GEMM_TILE");
     force = e ? atoi(e) : 0;
@@ -465,6 +667,14 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemdma);
     if (r != hipSuccess) return r;
+    const void* wk[4] = {reinterpret_cast<const void*>(gemm_bf16x3_wreg_kernel<1, 32>),
+                         reinterpret_cast<const void*>(gemm_bf16x3_wreg_kernel<4, 32>),
+                         reinterpret_cast<const void*>(gemm_bf16x3_wreg_kernel<1, 64>),
+                         reinterpret_cast<const void*>(gemm_bf16x3_wreg_kernel<4, 64>)};
+    for (int i = 0; i < 4; ++i) {
+      r = hipFuncSetAttribute(wk[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(i < 2 ? smemw32 : smemw64));
+      if (r != hipSuccess) return r;
+    }
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_pipe_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smempipe);
     if (r != hipSuccess) return r;
@@ -479,6 +689,19 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(gemm_bf16x3_pipe_kernel, dim3(nMt * nNt), dim3(PNT), smempipe, s, a, nMt, nNt, w);
     return hipGetLastError();
   }
+  if (force != 1 && force != 128 && taps_ok) {   // default: weights-in-registers kernel
+    const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
+    const dim3 grid(nMt * nNt), block(256);
+    if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
+    if (a.pool_part) {                    // fused pooling needs the whole 64-frame tile staged: 2 workgroups / CU
+      if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_wreg_kernel<1, 64>), grid, block, smemw64, s, a, nMt, nNt, w, diag);
+      else        hipLaunchKernelGGL((gemm_bf16x3_wreg_kernel<4, 64>), grid, block, smemw64, s, a, nMt, nNt, w, diag);
+    } else {                              // 8 KB of epilogue scratch per wave: 3 workgroups / CU
+      if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_wreg_kernel<1, 32>), grid, block, smemw32, s, a, nMt, nNt, w, diag);
+      else        hipLaunchKernelGGL((gemm_bf16x3_wreg_kernel<4, 32>), grid, block, smemw32, s, a, nMt, nNt, w, diag);
+    }
+    return hipGetLastError();
+  }
   if (force != 128 && taps_ok) {
     const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
     hipLaunchKernelGGL(gemm_bf16x3_dma_kernel, dim3(nMt * nNt), dim3(256), smemdma, s, a, nMt, nNt, w, diag);
@@ -490,3 +713,12 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s) {
 }
 
 }  // namespace xv
+
+// debug only (not part of the public ABI): copy the phase stamps of the last traced GEMM launch
+extern "C" int xvdbg_gemm_trace(long long* out, int max_wgs) {
+  if (!xv::g_trace || xv::g_trace_wgs <= 0) return 0;
+  const int n = xv::g_trace_wgs < max_wgs ? xv::g_trace_wgs : max_wgs;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(out, xv::g_trace, sizeof(long long) * 4 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return n;
+}

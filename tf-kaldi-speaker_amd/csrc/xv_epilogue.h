@@ -80,18 +80,32 @@ __device__ __forceinline__ void store_tile_scalar(const GemmArgs& p, const f32x1
   }
 }
 
+// Ordering point between a wave's own LDS writes and its cross-lane read-back.  The scratch is private to the
+// wave and DS instructions of one wave execute in order, so no workgroup barrier (and no s_barrier at all) is
+// needed -- only that the compiler keeps the program order.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // LDS-staged epilogue of a 64x64 wave tile acc[ni][mi] (2x2 MFMA tiles, orientation above).
-// The wave writes its post-activation tile into a private 16 KB LDS scratch shaped like the
+// The wave writes its post-activation tile into a private LDS scratch shaped like the
 // destination rows (256 bytes per frame: two SB blocks, or 64 floats; 16-byte chunks XOR-swizzled
 // by frame & 15), then reads it back 16 bytes per lane and stores whole 256-byte row segments.
-// Requirements (wide_epilogue_ok): N % 4 == 0, ldy % 4 == 0, 16-byte aligned Y.  All waves of the
-// workgroup call it (contains __syncthreads()); `lds` is the workgroup's LDS base, >= 16 KB per
-// wave, no longer read by the main loop.
-template <int ACT>
-__device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f32x16 (&acc)[2][2], int mbase, int nbase,
+// ROWS = frames staged per pass: 64 (16 KB of scratch per wave, one pass; required by the fused pooling)
+// or 32 (8 KB per wave, two passes -- lets three workgroups share a CU's LDS).
+// Requirements (wide_epilogue_ok): N % 4 == 0, ldy % 4 == 0, 16-byte aligned Y.  `lds` is the workgroup's
+// LDS base, ROWS * 256 bytes per wave, no longer read by the main loop (the caller's last K-loop barrier
+// guarantees that); there is no workgroup barrier inside.
+// MI = 32-frame MFMA tiles per wave along M (2: 64-frame wave tile; 1: the half-height tail tiles).
+template <int ACT, int ROWS, int MI>
+__device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f32x16 (&acc)[2][MI], int mbase, int nbase,
                                                      int lane, int wave, char* lds) {
+  static_assert((ROWS == 64 || ROWS == 32) && ROWS <= 32 * MI, "ROWS");
+  constexpr int NPASS = 32 * MI / ROWS, MIP = ROWS / 32;      // passes, MFMA row tiles per pass
   const int r32 = lane & 31, h = lane >> 5;
-  char* scratch = lds + wave * 16384;
+  char* scratch = lds + wave * (ROWS * 256);
   const int rrow = lane >> 4, rchunk = lane & 15;       // read-back map: 4 frames x 16 chunks per pass
 
   auto value4 = [&](const f32x16& t, int q, const f32x4& sc, const f32x4& sh, const f32x4& al) -> f32x4 {
@@ -113,120 +127,128 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
     sh = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
     al = (ok && p.alpha) ? *reinterpret_cast<const f32x4*>(p.alpha + n4) : z;
   };
+  // stage fp32 values of pass `ps` (post-activation unless `pre_act`): chunk ni*8 + 2q + h of frame row
+  auto stage_f32 = [&](int ps, bool pre_act) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 sc, sh, al;
+        params(nbase + ni * 32 + 8 * q + 4 * h, sc, sh, al);
+#pragma unroll
+        for (int ml = 0; ml < MIP; ++ml) {
+          const int row = ml * 32 + r32;
+          const f32x16& t = acc[ni][ps * MIP + ml];
+          f32x4 v;
+          if (pre_act) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaf(t[4 * q + i], sc[i], sh[i]);
+          } else {
+            v = value4(t, q, sc, sh, al);
+          }
+          *reinterpret_cast<f32x4*>(scratch + row * 256 + (((ni * 8 + 2 * q + h) ^ (row & 15)) << 4)) = v;
+        }
+      }
+  };
 
   if (p.R) {
     // residual form (model/resnet.py:84-85,147-148): y = act(bn(conv) + shortcut).  Stage the BN output in
     // LDS, then add the fp32 shortcut row-wise (coalesced 16-byte loads), activate, and store fp32 / SB.
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 sc, sh, al;
-        params(nbase + ni * 32 + 8 * q + 4 * h, sc, sh, al);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const int row = mi * 32 + r32;
-          f32x4 v;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = fmaf(acc[ni][mi][4 * q + i], sc[i], sh[i]);
-          *reinterpret_cast<f32x4*>(scratch + row * 256 + (((ni * 8 + 2 * q + h) ^ (row & 15)) << 4)) = v;
-        }
-      }
-    __syncthreads();
     const int n = nbase + rchunk * 4;
     const bool nok = n < p.N;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     const f32x4 al4 = (nok && p.alpha) ? *reinterpret_cast<const f32x4*>(p.alpha + n) : z;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 4 + rrow;
-      const int m = mbase + row;
-      f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
-      int orow = -1;
-      if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
-      if (orow < 0) continue;
-      if (nok) {
-        v += *reinterpret_cast<const f32x4*>(p.R + (int64_t)orow * p.ldr + n);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], p.act, al4[i]);
-        if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
-      } else {
-        v = z;
+    for (int ps = 0; ps < NPASS; ++ps) {
+      stage_f32(ps, true);
+      wave_lds_sync();
+#pragma unroll 4
+      for (int it = 0; it < ROWS / 4; ++it) {
+        const int row = it * 4 + rrow;
+        const int m = mbase + ps * ROWS + row;
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
+        int orow = -1;
+        if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+        if (orow < 0) continue;
+        if (nok) {
+          v += *reinterpret_cast<const f32x4*>(p.R + (int64_t)orow * p.ldr + n);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], p.act, al4[i]);
+          if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
+        } else {
+          v = z;
+        }
+        if (p.Ysb && n < p.ldsb) {
+          uint32_t h01, l01, h23, l23;
+          split2(v[0], v[1], h01, l01);
+          split2(v[2], v[3], h23, l23);
+          char* blk = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128 + (n & 31) * 2;
+          *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
+        }
       }
-      if (p.Ysb && n < p.ldsb) {
-        uint32_t h01, l01, h23, l23;
-        split2(v[0], v[1], h01, l01);
-        split2(v[2], v[3], h23, l23);
-        char* blk = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128 + (n & 31) * 2;
-        *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
-      }
+      wave_lds_sync();
     }
     return;
   }
   if (p.Ysb) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 sc, sh, al;
-        params(nbase + ni * 32 + 8 * q + 4 * h, sc, sh, al);     // padding channels: scale = shift = 0 -> 0
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const f32x4 v = value4(acc[ni][mi], q, sc, sh, al);
-          uint32_t h01, l01, h23, l23;
-          split2(v[0], v[1], h01, l01);
-          split2(v[2], v[3], h23, l23);
-          const int row = mi * 32 + r32;
-          char* rp = scratch + row * 256 + 8 * h;
-          *reinterpret_cast<uint2*>(rp + (((ni * 8 + q) ^ (row & 15)) << 4)) = make_uint2(h01, h23);
-          *reinterpret_cast<uint2*>(rp + (((ni * 8 + 4 + q) ^ (row & 15)) << 4)) = make_uint2(l01, l23);
-        }
-      }
-    __syncthreads();
     const bool blk_ok = nbase + (rchunk >> 3) * 32 < p.ldsb;     // SB block exists in the output row
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 sc, sh, al;
+          params(nbase + ni * 32 + 8 * q + 4 * h, sc, sh, al);     // padding channels: scale = shift = 0 -> 0
+#pragma unroll
+          for (int ml = 0; ml < MIP; ++ml) {
+            const f32x4 v = value4(acc[ni][ps * MIP + ml], q, sc, sh, al);
+            uint32_t h01, l01, h23, l23;
+            split2(v[0], v[1], h01, l01);
+            split2(v[2], v[3], h23, l23);
+            const int row = ml * 32 + r32;
+            char* rp = scratch + row * 256 + 8 * h;
+            *reinterpret_cast<uint2*>(rp + (((ni * 8 + q) ^ (row & 15)) << 4)) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(rp + (((ni * 8 + 4 + q) ^ (row & 15)) << 4)) = make_uint2(l01, l23);
+          }
+        }
+      wave_lds_sync();
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 4 + rrow;
-      const int m = mbase + row;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
-      int orow = -1;
-      if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
-      if (orow >= 0 && blk_ok)
-        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (nbase >> 5) * 128 +
-                                  rchunk * 16) = v;
+      for (int it = 0; it < ROWS / 4; ++it) {
+        const int row = it * 4 + rrow;
+        const int m = mbase + ps * ROWS + row;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
+        int orow = -1;
+        if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+        if (orow >= 0 && blk_ok)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (nbase >> 5) * 128 +
+                                    rchunk * 16) = v;
+      }
+      wave_lds_sync();
     }
-    if (p.Y) __syncthreads();
   }
   if (p.Y || p.pool_part) {
+    const int n = nbase + rchunk * 4;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 sc, sh, al;
-        params(nbase + ni * 32 + 8 * q + 4 * h, sc, sh, al);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const int row = mi * 32 + r32;
-          *reinterpret_cast<f32x4*>(scratch + row * 256 + (((ni * 8 + 2 * q + h) ^ (row & 15)) << 4)) =
-              value4(acc[ni][mi], q, sc, sh, al);
+    for (int ps = 0; ps < NPASS; ++ps) {
+      stage_f32(ps, false);
+      wave_lds_sync();
+      if (p.Y) {
+#pragma unroll 4
+        for (int it = 0; it < ROWS / 4; ++it) {
+          const int row = it * 4 + rrow;
+          const int m = mbase + ps * ROWS + row;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
+          int orow = -1;
+          if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+          if (orow >= 0 && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
         }
       }
-    __syncthreads();
-  }
-  if (p.Y) {
-    const int n = nbase + rchunk * 4;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 4 + rrow;
-      const int m = mbase + row;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
-      int orow = -1;
-      if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
-      if (orow >= 0 && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
+      if (NPASS > 1) wave_lds_sync();
     }
   }
-  if (p.pool_part) {
+  if (ROWS == 64 && MI == 2 && p.pool_part) {
     // fused statistics pooling: lane = channel; for every utterance segment inside the 64-frame
     // tile store (sum x, sum (x - segment mean)^2) -- two passes over the LDS copy, so the merge in
     // pool_finalize_kernel (Chan et al.) is as accurate as the reference's two-pass variance.
@@ -290,21 +312,23 @@ __device__ __forceinline__ bool wide_epilogue_ok(const GemmArgs& p) {
 }
 
 // Epilogue entry for a 64x64 wave tile: LDS-staged wide stores when the shape allows, scalar otherwise.
-__device__ __forceinline__ void store_wave_tile(const GemmArgs& p, const f32x16 (&acc)[2][2], int mbase, int nbase,
+// ROWS = 32 must not be used for a launch with pool_part (the fused pooling needs the whole tile staged).
+template <int ROWS = 64, int MI = 2>
+__device__ __forceinline__ void store_wave_tile(const GemmArgs& p, const f32x16 (&acc)[2][MI], int mbase, int nbase,
                                                 int lane, int wave, char* lds) {
   if (wide_epilogue_ok(p)) {
     if (p.act == ACT_RELU)
-      store_wave_tile_impl<ACT_RELU>(p, acc, mbase, nbase, lane, wave, lds);
+      store_wave_tile_impl<ACT_RELU, ROWS, MI>(p, acc, mbase, nbase, lane, wave, lds);
     else if (p.act == ACT_NONE)
-      store_wave_tile_impl<ACT_NONE>(p, acc, mbase, nbase, lane, wave, lds);
+      store_wave_tile_impl<ACT_NONE, ROWS, MI>(p, acc, mbase, nbase, lane, wave, lds);
     else
-      store_wave_tile_impl<-1>(p, acc, mbase, nbase, lane, wave, lds);
+      store_wave_tile_impl<-1, ROWS, MI>(p, acc, mbase, nbase, lane, wave, lds);
     return;
   }
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) store_tile_scalar(p, acc[ni][mi], mbase + mi * 32, nbase + ni * 32, lane);
+    for (int mi = 0; mi < MI; ++mi) store_tile_scalar(p, acc[ni][mi], mbase + mi * 32, nbase + ni * 32, lane);
 }
 
 }  // namespace xv

@@ -40,6 +40,8 @@ struct GemmArgs {
   void* Ysb;              // SB output or nullptr
   int ldsb;               // channels per SB output row incl. zero padding (multiple of 32)
   const void* Wsb;        // packed weights in SB format [Npad][Kpad/32][128 bytes]
+  const void* Wfr = nullptr;   // weights, MFMA-fragment-major (gemm_bf16x3_wreg_kernel)
+  long long* trace = nullptr;  // debug: per-workgroup phase timestamps (XVEC_TRACE_K), 4 per workgroup
   // split-K (fp32 kernel, small-M segment layers): slice s of `ksplit` accumulates K tiles
   // [s*kper, (s+1)*kper) and writes RAW accumulators to partial[s][M][Npad]; a reduce kernel
   // sums the slices in order (deterministic) and applies the epilogue.

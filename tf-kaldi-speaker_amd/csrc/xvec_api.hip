@@ -73,6 +73,7 @@ struct Layer {
   int act = ACT_NONE;         // activation of the final stage
   // device
   DevBuf wt;                  // fp32 [Npad][Kpad]                      (fp32 MFMA kernel)
+  DevBuf wfr;                 // same values, MFMA-fragment-major: [Npad/32][Kpad/32][plane*2+ks][64 lanes][16 B]
   DevBuf wsb;                 // split-blocked bf16 hi/lo [Npad][Kpad/32][128 B] (bf16x3 kernel)
   bool use_split = false;     // this layer runs on the bf16x3 kernel
   bool im2col = false;        // first layer in bf16x3 mode: fp32 frames -> SB im2col rows -> dense split GEMM
@@ -566,6 +567,19 @@ int upload_layer(xv_handle* h, Layer& L) {
       }
     XV_HIP(h, L.wsb.alloc(elems * 4));
     XV_HIP(h, hipMemcpy(L.wsb.p, sb.data(), elems * 4, hipMemcpyHostToDevice));
+    // fragment-major copy for the weights-in-registers kernel: one global_load_dwordx4 of a wave = 1 KB contiguous
+    std::vector<uint16_t> fr(elems * 2, 0);
+    const size_t nkb = L.Kpad / 32;
+    for (size_t n = 0; n < (size_t)L.Npad; ++n)
+      for (size_t kb = 0; kb < nkb; ++kb)
+        for (int q = 0; q < 8; ++q) {                       // SB chunk q = plane*4 + ks*2 + half
+          const int plane = q >> 2, ks = (q >> 1) & 1, hh = q & 1;
+          const size_t src = (n * nkb + kb) * 64 + (size_t)q * 8;
+          const size_t dst = ((((n / 32) * nkb + kb) * 4 + plane * 2 + ks) * 64 + hh * 32 + (n & 31)) * 8;
+          for (int e = 0; e < 8; ++e) fr[dst + e] = sb[src + e];
+        }
+    XV_HIP(h, L.wfr.alloc(elems * 4));
+    XV_HIP(h, hipMemcpy(L.wfr.p, fr.data(), elems * 4, hipMemcpyHostToDevice));
   }
   return XV_OK;
 }
@@ -1127,7 +1141,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           a.cin = 32; a.K = 32;             // taps 9..31 are zero in both operands
           if (L.use_split) {
             XV_HIP(h, launch_im2col2d_sb(feats, feat_ld, off, B, L.Fout, st.M, ws + st.scratch_off, s));
-            a.Xsb = ws + st.scratch_off; a.ldsbx = 32; a.Wsb = L.wsb.p;
+            a.Xsb = ws + st.scratch_off; a.ldsbx = 32; a.Wsb = L.wsb.p; a.Wfr = L.wfr.p;
             XV_HIP(h, launch_gemm_bf16x3(a, s));
           } else {
             XV_HIP(h, launch_im2col2d_f32(feats, feat_ld, off, B, L.Fout, st.M, reinterpret_cast<float*>(ws + st.scratch_off), s));
@@ -1147,7 +1161,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           a.Xsb = ws + st.scratch_off;
           a.ldsbx = L.Kpad;
           a.cin = a.K;
-          a.Wsb = L.wsb.p;
+          a.Wsb = L.wsb.p; a.Wfr = L.wfr.p;
           XV_HIP(h, launch_gemm_bf16x3(a, s));
           break;
         }
@@ -1155,7 +1169,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           if (st.in0_sb_off < 0) return fail(h, XV_ERR_STATE, "split layer %s has no split-blocked input", L.kernel_name.c_str());
           a.Xsb = ws + st.in0_sb_off;
           a.ldsbx = L.mode == 0 ? sb_ld(L.cin) : 0;
-          a.Wsb = L.wsb.p;
+          a.Wsb = L.wsb.p; a.Wfr = L.wfr.p;
           XV_HIP(h, launch_gemm_bf16x3(a, s));
           if (st.unpad_to_out)
             XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.cols,
@@ -1307,7 +1321,7 @@ void xv_destroy(xv_handle* h) {
   if (!h) return;
   {
     DeviceGuard g(h->device);
-    for (auto& L : h->layers) { L.wt.release(); L.wsb.release(); L.vec.release(); }
+    for (auto& L : h->layers) { L.wt.release(); L.wsb.release(); L.wfr.release(); L.vec.release(); }
     h->query.release();
     h->post_vec.release();
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
