@@ -466,6 +466,167 @@ __device__ __forceinline__ void wreg_tile(const GemmArgs& p, int m0, int n0, int
   stamp(3);
 }
 
+// ------------------------------------------------------------------------------------------
+// Same tile, same data movement, but every vector-memory instruction of the K loop is inline assembly and
+// every wait is an explicit s_waitcnt vmcnt(N) with an exact count.  The compiler-scheduled form above has to
+// drain the counter (vmcnt(0)) at the top of every step, so the weight fragment loaded LAST in step s has an
+// eighth of a step to land and a workgroup cannot go faster than ~1.16 us per step (tools/gemm_trace.py); three
+// such workgroups barely cover the matrix pipe.  Here fragment k of step s+1 is loaded in MFMA group k of step
+// s and first used in group k' of step s+1 -- in issue order, so each load has a whole step to land:
+//   VMEM order per step:  D x NPS (slab pieces, group 0) , a0 .. a7 (one per group)
+//   a0,a1 = (nj0; hi,lo; ks0)  a2,a3 = (nj1; ks0)  a4,a5 = (nj0; ks1)  a6,a7 = (nj1; ks1)
+//   step s+1: before group 0 wait vmcnt(7+NPS) [a0,a1] ; group 1 vmcnt(6+NPS) [a2,a3] ;
+//             group 4 vmcnt(7+NPS) [a4,a5] ; group 5 vmcnt(6+NPS) [a6,a7] ; slab switch vmcnt(8) [all D].
+// The counts rely on LDS-DMA loads and register loads retiring in issue order under the one counter
+// (checked on hardware: tools/vmcnt_order_test.hip, 0 violations in 2.6e8 trials).  The waits name the registers
+// they release as "+v" operands, so the compiler cannot move an MFMA above its wait.
+#define XV_GLD(dst, ptr, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(dst) : "v"(ptr))
+#define XV_WAIT2(N, ra, rb) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra), "+v"(rb) : "n"(N))
+
+template <int NPS, int EROWS>
+__device__ __forceinline__ void wreg_tile_asm(const GemmArgs& p, int m0, int n0, int w, char* smem3) {
+  char* As = smem3;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, h = lane >> 5;
+
+  const int ncb = (p.Kpad >> 5) / w;
+  const int nsteps = ncb * w;
+  const int ngroups = (BM + w - 1 + 7) >> 3;
+  const int lrow = lane >> 3, lpc = lane & 7;
+  const int64_t a_row_bytes = (p.a_pitch ? p.a_pitch : p.ldsbx) * 4;
+  const int kbt = p.a_pitch ? (p.ktap >> 5) : (p.Kpad >> 5);
+  const int64_t tap_bytes = p.a_pitch ? p.tap_stride * 4 : 0;
+  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(m0 + lrow) * a_row_bytes;
+  const int64_t nkb4k = (int64_t)(p.Kpad >> 5) * 4096;
+  const char* Wg0 = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((n0 + wn * 64) >> 5) * nkb4k + lane * 16;
+  const char* Wg1 = Wg0 + nkb4k;
+  const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr_t)As;
+
+  auto dma_a = [&](int64_t koff, int buf, int g) {      // slab group g (8 rows x 128 B) -> LDS, untracked by the compiler
+    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
+    const char* src = Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * DA_BYTES + g * 1024);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto stamp = [&](int i) {
+#ifdef XV_GEMM_TRACE
+    if (p.trace && tid == 0) p.trace[(int64_t)blockIdx.x * 4 + i] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  };
+  stamp(0);
+  bf16x8 W0[8], W1[8];
+  XV_GLD(W0[0], Wg0, 0); XV_GLD(W0[1], Wg0, 1024); XV_GLD(W0[2], Wg0, 2048); XV_GLD(W0[3], Wg0, 3072);
+  XV_GLD(W0[4], Wg1, 0); XV_GLD(W0[5], Wg1, 1024); XV_GLD(W0[6], Wg1, 2048); XV_GLD(W0[7], Wg1, 3072);
+  for (int g = wave; g < ngroups; g += 4) dma_a(0, 0, g);
+  int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : 128;
+  int blk_next = (kbt == 1 && p.a_pitch) ? 0 : 1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  stamp(1);
+  int cb = 0, j = 0;
+  auto step = [&](int s, bf16x8 (&Wc)[8], bf16x8 (&Wn)[8]) __attribute__((always_inline)) {
+    int cb_next = cb, j_next = j + 1;
+    if (j_next == w) { j_next = 0; cb_next = cb + 1; }
+    const int kbn = s + 1 < nsteps ? j_next * ncb + cb_next : 0;     // unconditional issue (the counts are static)
+    const char* q0 = Wg0 + (int64_t)kbn * 4096;
+    const char* q1 = Wg1 + (int64_t)kbn * 4096;
+    const char* ab = As + (cb & 1) * DA_BYTES;
+    int aoff[2], aswz[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int ra = wm * 64 + mi * 32 + r32 + j;
+      aoff[mi] = ra * DROW;
+      aswz[mi] = (ra >> 1) & 7;
+    }
+    bf16x8 ah[2][2], al[2][2];           // [ks][mi]
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      ah[0][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + ((h ^ aswz[mi]) << 4));
+      al[0][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((4 + h) ^ aswz[mi]) << 4));
+    }
+    {                                    // slab piece(s) of the next channel block: oldest VMEM of the step
+      const int64_t ksrc = cb + 1 < ncb ? koff_next : 0;      // last block: harmless re-stage into the idle buffer
+#pragma unroll
+      for (int i = 0; i < NPS; ++i) dma_a(ksrc, (cb + 1) & 1, min((j * NPS + i) * 4 + wave, ngroups - 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      // a_g: fragment index f = nj*4 + plane*2 + ks in the order it is needed next step
+      if (g == 0) XV_GLD(Wn[0], q0, 0);
+      if (g == 1) XV_GLD(Wn[2], q0, 2048);
+      if (g == 2) XV_GLD(Wn[4], q1, 0);
+      if (g == 3) XV_GLD(Wn[6], q1, 2048);
+      if (g == 4) XV_GLD(Wn[1], q0, 1024);
+      if (g == 5) XV_GLD(Wn[3], q0, 3072);
+      if (g == 6) XV_GLD(Wn[5], q1, 1024);
+      if (g == 7) XV_GLD(Wn[7], q1, 3072);
+      if (g < 4) {                       // ks = 1 activation fragments trickle in behind the ks = 0 MFMAs
+        const int mi = g >> 1;
+        if (g & 1) al[1][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((6 + h) ^ aswz[mi]) << 4));
+        else       ah[1][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((2 + h) ^ aswz[mi]) << 4));
+      }
+      if (g == 0) XV_WAIT2(7 + NPS, Wc[0], Wc[2]);
+      if (g == 1) XV_WAIT2(6 + NPS, Wc[4], Wc[6]);
+      if (g == 4) XV_WAIT2(7 + NPS, Wc[1], Wc[3]);
+      if (g == 5) XV_WAIT2(6 + NPS, Wc[5], Wc[7]);
+#pragma unroll
+      for (int t = 3 * g; t < 3 * g + 3; ++t) {
+        const int ks = t / 12, rem = t % 12, mi = rem / 6, nj = (rem / 3) & 1, term = rem % 3;
+        const bf16x8 wh = Wc[nj * 4 + ks], wl = Wc[nj * 4 + 2 + ks];
+        if (term == 0) acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al[ks][mi], acc[nj][mi], 0, 0, 0);
+        if (term == 1) acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah[ks][mi], acc[nj][mi], 0, 0, 0);
+        if (term == 2) acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah[ks][mi], acc[nj][mi], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (cb_next != cb) {                 // slab switch: every slab piece issued so far has landed (8 newer loads may fly)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __syncthreads();
+      if (++blk_next == kbt) {
+        blk_next = 0;
+        koff_next += tap_bytes - (int64_t)(kbt - 1) * 128;
+      } else {
+        koff_next += 128;
+      }
+    }
+    cb = cb_next;
+    j = j_next;
+  };
+  for (int s = 0; s < nsteps; s += 2) {
+    step(s, W0, W1);
+    if (s + 1 < nsteps) step(s + 1, W1, W0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dummy loads of the last step still target W registers
+  __builtin_amdgcn_sched_barrier(0);
+  stamp(2);
+  store_wave_tile<EROWS, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, smem3);
+  stamp(3);
+}
+#undef XV_GLD
+#undef XV_WAIT2
+
+template <int NPS, int EROWS>
+__global__ __launch_bounds__(256, EROWS == 32 ? 3 : 2) void gemm_bf16x3_wasm_kernel(GemmArgs p, int nMt, int nNt, int w) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
+  const int mt = tile / nNt, nt = tile - mt * nNt;
+  wreg_tile_asm<NPS, EROWS>(p, mt * BM, nt * BN, w, smem3);
+}
+
 template <int NPS, int EROWS>
 __global__ __launch_bounds__(256, EROWS == 32 ? 3 : 2) void gemm_bf16x3_wreg_kernel(GemmArgs p, int nMt, int nNt, int w, int diag) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
@@ -651,7 +812,7 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
       if (g_trace && wgs <= kTraceWgs) { a.trace = g_trace; g_trace_wgs = wgs; }
     }
   }
-  static int force = -1;        // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA 128x128 | 256 pipelined 256x128; 0 = default (weights in registers)
+  static int force = -1;        // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA 128x128 | 2 weights-in-registers, compiler waits | 256 pipelined 256x128; 0 = default (weights in registers, counted waits)
   static bool attr_set = false;
   static int diag = 0;              // XVEC_GEMM_DIAG: timing-only ablation switches (outputs invalid)
   const size_t smem128 = (size_t)4 * TILE_B;
@@ -671,8 +832,14 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
                          reinterpret_cast<const void*>(gemm_bf16x3_wreg_kernel<4, 32>),
                          reinterpret_cast<const void*>(gemm_bf16x3_wreg_kernel<1, 64>),
                          reinterpret_cast<const void*>(gemm_bf16x3_wreg_kernel<4, 64>)};
+    const void* wa[4] = {reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<1, 32>),
+                         reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<4, 32>),
+                         reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<1, 64>),
+                         reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<4, 64>)};
     for (int i = 0; i < 4; ++i) {
       r = hipFuncSetAttribute(wk[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(i < 2 ? smemw32 : smemw64));
+      if (r != hipSuccess) return r;
+      r = hipFuncSetAttribute(wa[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(i < 2 ? smemw32 : smemw64));
       if (r != hipSuccess) return r;
     }
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_pipe_kernel),
@@ -689,7 +856,20 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
     hipLaunchKernelGGL(gemm_bf16x3_pipe_kernel, dim3(nMt * nNt), dim3(PNT), smempipe, s, a, nMt, nNt, w);
     return hipGetLastError();
   }
-  if (force != 1 && force != 128 && taps_ok) {   // default: weights-in-registers kernel
+  if (force != 1 && force != 2 && force != 128 && taps_ok) {   // default: weights in registers, hand-counted waits
+    const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
+    const dim3 grid(nMt * nNt), block(256);
+    if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
+    if (a.pool_part) {
+      if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_wasm_kernel<1, 64>), grid, block, smemw64, s, a, nMt, nNt, w);
+      else        hipLaunchKernelGGL((gemm_bf16x3_wasm_kernel<4, 64>), grid, block, smemw64, s, a, nMt, nNt, w);
+    } else {
+      if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_wasm_kernel<1, 32>), grid, block, smemw32, s, a, nMt, nNt, w);
+      else        hipLaunchKernelGGL((gemm_bf16x3_wasm_kernel<4, 32>), grid, block, smemw32, s, a, nMt, nNt, w);
+    }
+    return hipGetLastError();
+  }
+  if (force == 2 && taps_ok) {                   // A/B: the compiler-scheduled form of the same kernel
     const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
     const dim3 grid(nMt * nNt), block(256);
     if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
