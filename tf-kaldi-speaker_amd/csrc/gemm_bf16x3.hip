@@ -616,6 +616,132 @@ __device__ __forceinline__ void wreg_tile_asm(const GemmArgs& p, int m0, int n0,
   store_wave_tile<EROWS, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, smem3);
   stamp(3);
 }
+// ------------------------------------------------------------------------------------------
+// "1 x 4" wave layout of the same kernel: every wave owns ONE 32-channel block and all 128 frames of the tile.
+// In the 2 x 2 layout above the two waves of a pair load identical weight fragments; the L1 counters show the
+// second request landing on a line that is still in flight 36 % of all L1 cycles (TCP_PENDING_STALL_CYCLES,
+// profiles/r01/pmc_tcp1_wreg.txt) and the texture addresser busy 62 % of the kernel.  Here every weight byte is
+// requested exactly once per workgroup (4 loads per wave and step instead of 8); the price is that all four
+// waves read the whole activation slab from LDS (16 ds_read_b128 per wave and step instead of 8), which the LDS
+// has room for (halving the LDS reads of the 2 x 2 kernel changed nothing).
+//   VMEM order per step:  D x NPS (top) , a0 (group 0) a1 (group 2) a2 (group 4) a3 (group 6)
+//   a0,a1 = (hi,lo; ks0)  a2,a3 = (hi,lo; ks1);  group g = (ks, mi) = (g >> 2, g & 3), 3 MFMAs each
+//   step s+1: before group 0 wait vmcnt(3+NPS) [a0,a1] ; before group 4 vmcnt(3+NPS) [a2,a3] ; slab switch vmcnt(4).
+template <int NPS>
+__device__ __forceinline__ void w14_tile(const GemmArgs& p, int m0, int n0, int w, char* smem3) {
+  char* As = smem3;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+
+  const int ncb = (p.Kpad >> 5) / w;
+  const int nsteps = ncb * w;
+  const int ngroups = (BM + w - 1 + 7) >> 3;
+  const int lrow = lane >> 3, lpc = lane & 7;
+  const int64_t a_row_bytes = (p.a_pitch ? p.a_pitch : p.ldsbx) * 4;
+  const int kbt = p.a_pitch ? (p.ktap >> 5) : (p.Kpad >> 5);
+  const int64_t tap_bytes = p.a_pitch ? p.tap_stride * 4 : 0;
+  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(m0 + lrow) * a_row_bytes;
+  const int64_t nkb4k = (int64_t)(p.Kpad >> 5) * 4096;
+  const char* Wg = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((n0 >> 5) + wave) * nkb4k + lane * 16;
+  const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr_t)As;
+
+  auto dma_a = [&](int64_t koff, int buf, int g) {
+    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
+    const char* src = Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * DA_BYTES + g * 1024);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  bf16x8 W0[4], W1[4];                   // [plane * 2 + ks]
+  XV_GLD(W0[0], Wg, 0); XV_GLD(W0[1], Wg, 1024); XV_GLD(W0[2], Wg, 2048); XV_GLD(W0[3], Wg, 3072);
+  for (int g = wave; g < ngroups; g += 4) dma_a(0, 0, g);
+  int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : 128;
+  int blk_next = (kbt == 1 && p.a_pitch) ? 0 : 1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cb = 0, j = 0;
+  auto step = [&](int s, bf16x8 (&Wc)[4], bf16x8 (&Wn)[4]) __attribute__((always_inline)) {
+    int cb_next = cb, j_next = j + 1;
+    if (j_next == w) { j_next = 0; cb_next = cb + 1; }
+    const int kbn = s + 1 < nsteps ? j_next * ncb + cb_next : 0;
+    const char* q = Wg + (int64_t)kbn * 4096;
+    const char* ab = As + (cb & 1) * DA_BYTES;
+    int aoff[4], aswz[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int ra = mi * 32 + r32 + j;
+      aoff[mi] = ra * DROW;
+      aswz[mi] = (ra >> 1) & 7;
+    }
+    bf16x8 fh[8], fl[8];                 // activation fragments of group g = ks * 4 + mi, read two groups ahead
+    auto read_frag = [&](int g) {
+      const int ks = g >> 2, mi = g & 3;
+      fh[g] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((ks * 2 + h) ^ aswz[mi]) << 4));
+      fl[g] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((4 + ks * 2 + h) ^ aswz[mi]) << 4));
+    };
+    read_frag(0);
+    read_frag(1);
+    {
+      const int64_t ksrc = cb + 1 < ncb ? koff_next : 0;
+#pragma unroll
+      for (int i = 0; i < NPS; ++i) dma_a(ksrc, (cb + 1) & 1, min((j * NPS + i) * 4 + wave, ngroups - 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g == 0) XV_GLD(Wn[0], q, 0);        // hi ks0
+      if (g == 2) XV_GLD(Wn[2], q, 2048);     // lo ks0
+      if (g == 4) XV_GLD(Wn[1], q, 1024);     // hi ks1
+      if (g == 6) XV_GLD(Wn[3], q, 3072);     // lo ks1
+      if (g + 2 < 8) read_frag(g + 2);
+      if (g == 0) XV_WAIT2(3 + NPS, Wc[0], Wc[2]);
+      if (g == 4) XV_WAIT2(3 + NPS, Wc[1], Wc[3]);
+      const int ks = g >> 2, mi = g & 3;
+      const bf16x8 wh = Wc[ks], wl = Wc[2 + ks];
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, fl[g], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, fh[g], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, fh[g], acc[mi], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (cb_next != cb) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __syncthreads();
+      if (++blk_next == kbt) {
+        blk_next = 0;
+        koff_next += tap_bytes - (int64_t)(kbt - 1) * 128;
+      } else {
+        koff_next += 128;
+      }
+    }
+    cb = cb_next;
+    j = j_next;
+  };
+  for (int s = 0; s < nsteps; s += 2) {
+    step(s, W0, W1);
+    if (s + 1 < nsteps) step(s + 1, W1, W0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  store_wave_tile_n32<64>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
+}
+
+template <int NPS>
+__global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14_kernel(GemmArgs p, int nMt, int nNt, int w) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
+  const int mt = tile / nNt, nt = tile - mt * nNt;
+  w14_tile<NPS>(p, mt * BM, nt * BN, w, smem3);
+}
+
 #undef XV_GLD
 #undef XV_WAIT2
 
@@ -812,7 +938,7 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
       if (g_trace && wgs <= kTraceWgs) { a.trace = g_trace; g_trace_wgs = wgs; }
     }
   }
-  static int force = -1;        // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA 128x128 | 2 weights-in-registers, compiler waits | 256 pipelined 256x128; 0 = default (weights in registers, counted waits)
+  static int force = -1;        // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA 128x128 | 2 weights-in-registers 2x2 waves, compiler waits | 3 the same with counted waits | 256 pipelined 256x128; 0 = default (weights in registers, 1x4 waves, counted waits)
   static bool attr_set = false;
   static int diag = 0;              // XVEC_GEMM_DIAG: timing-only ablation switches (outputs invalid)
   const size_t smem128 = (size_t)4 * TILE_B;
@@ -836,6 +962,12 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
                          reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<4, 32>),
                          reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<1, 64>),
                          reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<4, 64>)};
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+    if (r != hipSuccess) return r;
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14_kernel<4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+    if (r != hipSuccess) return r;
     for (int i = 0; i < 4; ++i) {
       r = hipFuncSetAttribute(wk[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(i < 2 ? smemw32 : smemw64));
       if (r != hipSuccess) return r;
@@ -856,7 +988,14 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
     hipLaunchKernelGGL(gemm_bf16x3_pipe_kernel, dim3(nMt * nNt), dim3(PNT), smempipe, s, a, nMt, nNt, w);
     return hipGetLastError();
   }
-  if (force != 1 && force != 2 && force != 128 && taps_ok) {   // default: weights in registers, hand-counted waits
+  if (force != 1 && force != 2 && force != 3 && force != 128 && taps_ok) {   // default: 1 x 4 wave layout, weights in registers
+    const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
+    const dim3 grid(nMt * nNt), block(256);
+    if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14_kernel<1>), grid, block, smemw32, s, a, nMt, nNt, w);
+    else        hipLaunchKernelGGL((gemm_bf16x3_w14_kernel<4>), grid, block, smemw32, s, a, nMt, nNt, w);
+    return hipGetLastError();
+  }
+  if (force == 3 && taps_ok) {                   // A/B: 2 x 2 wave layout, weights in registers, counted waits
     const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
     const dim3 grid(nMt * nNt), block(256);
     if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;

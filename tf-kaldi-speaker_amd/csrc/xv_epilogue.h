@@ -304,6 +304,201 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
   }
 }
 
+// LDS-staged epilogue of a 128-frame x 32-channel wave tile acc[mi] (4 MFMA tiles stacked along M; the
+// "one wave per 32-channel block" layout of gemm_bf16x3_w14_kernel).  A row of the tile is exactly one SB block
+// (128 bytes) or 32 floats, so the scratch rows are 128 bytes (8 chunks, XOR-swizzled by frame & 7) and the
+// read-back hands 8 lanes one whole 128-byte line.  ROWS frames per pass (ROWS * 128 bytes of scratch per wave);
+// the fused statistics pooling needs ROWS == 64 (its partial slots are per 64-frame tile).
+template <int ACT, int ROWS>
+__device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
+                                                         int lane, int wave, char* lds) {
+  static_assert(ROWS == 32 || ROWS == 64 || ROWS == 128, "ROWS");
+  constexpr int NPASS = 128 / ROWS, MIP = ROWS / 32;
+  const int r32 = lane & 31, h = lane >> 5;
+  char* scratch = lds + wave * (ROWS * 128);
+  const int rrow = lane >> 3, rchunk = lane & 7;        // read-back map: 8 frames x 8 chunks per pass
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 sc[4], sh[4], al[4];                            // this lane's channels 8q + 4h .. +3, q = 0..3
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n4 = nbase + 8 * q + 4 * h;
+    if (p.raw) {
+      sc[q] = f32x4{1.f, 1.f, 1.f, 1.f};
+      sh[q] = z;
+      al[q] = z;
+    } else {
+      const bool ok = n4 < p.N;
+      sc[q] = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
+      sh[q] = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
+      al[q] = (ok && p.alpha) ? *reinterpret_cast<const f32x4*>(p.alpha + n4) : z;
+    }
+  }
+  auto value4 = [&](const f32x16& t, int q, bool pre_act) -> f32x4 {
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float y = fmaf(t[4 * q + i], sc[q][i], sh[q][i]);
+      v[i] = pre_act ? y : apply_act(y, ACT < 0 ? p.act : ACT, al[q][i]);
+    }
+    return v;
+  };
+  auto stage_f32 = [&](int ps, bool pre_act) {
+#pragma unroll
+    for (int ml = 0; ml < MIP; ++ml)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = ml * 32 + r32;
+        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((2 * q + h) ^ (row & 7)) << 4)) = value4(acc[ps * MIP + ml], q, pre_act);
+      }
+  };
+  const int n = nbase + rchunk * 4;                      // read-back channels of this lane (fp32 forms)
+
+  if (p.R) {
+    const bool nok = n < p.N;
+    const f32x4 al4 = (nok && p.alpha) ? *reinterpret_cast<const f32x4*>(p.alpha + n) : z;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      stage_f32(ps, true);
+      wave_lds_sync();
+#pragma unroll 4
+      for (int it = 0; it < ROWS / 8; ++it) {
+        const int row = it * 8 + rrow;
+        const int m = mbase + ps * ROWS + row;
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
+        int orow = -1;
+        if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+        if (orow < 0) continue;
+        if (nok) {
+          v += *reinterpret_cast<const f32x4*>(p.R + (int64_t)orow * p.ldr + n);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], p.act, al4[i]);
+          if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
+        } else {
+          v = z;
+        }
+        if (p.Ysb && n < p.ldsb) {
+          uint32_t h01, l01, h23, l23;
+          split2(v[0], v[1], h01, l01);
+          split2(v[2], v[3], h23, l23);
+          char* blk = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128 + (n & 31) * 2;
+          *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
+        }
+      }
+      wave_lds_sync();
+    }
+    return;
+  }
+  if (p.Ysb) {
+    const bool blk_ok = nbase < p.ldsb;                   // the SB block exists in the output row
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+      for (int ml = 0; ml < MIP; ++ml)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = value4(acc[ps * MIP + ml], q, false);   // padding channels: scale = shift = 0 -> 0
+          uint32_t h01, l01, h23, l23;
+          split2(v[0], v[1], h01, l01);
+          split2(v[2], v[3], h23, l23);
+          const int row = ml * 32 + r32;
+          char* rp = scratch + row * 128 + 8 * h;
+          *reinterpret_cast<uint2*>(rp + ((q ^ (row & 7)) << 4)) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(rp + (((4 + q) ^ (row & 7)) << 4)) = make_uint2(l01, l23);
+        }
+      wave_lds_sync();
+#pragma unroll 4
+      for (int it = 0; it < ROWS / 8; ++it) {
+        const int row = it * 8 + rrow;
+        const int m = mbase + ps * ROWS + row;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
+        int orow = -1;
+        if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+        if (orow >= 0 && blk_ok)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (nbase >> 5) * 128 +
+                                    rchunk * 16) = v;
+      }
+      wave_lds_sync();
+    }
+  }
+  if (p.Y || (ROWS == 64 && p.pool_part)) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      stage_f32(ps, false);
+      wave_lds_sync();
+      if (p.Y) {
+#pragma unroll 4
+        for (int it = 0; it < ROWS / 8; ++it) {
+          const int row = it * 8 + rrow;
+          const int m = mbase + ps * ROWS + row;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
+          int orow = -1;
+          if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+          if (orow >= 0 && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
+        }
+      }
+      if (ROWS == 64 && p.pool_part) {
+        // fused statistics pooling on the staged 64 frames x 32 channels (same (sum, M2 about the segment mean)
+        // partials per (utterance, 64-frame tile) slot as the 64x64 form): lane = (frame group rrow = t mod 8,
+        // 4 channels rchunk); the eight frame groups are combined with three xor-shuffles.
+        const int mb = mbase + ps * 64;
+        const bool nok = n < p.N;
+        const int my_utt = (mb + lane < p.M) ? p.pool_row2utt[mb + lane] : -1;
+        const int tile64 = mb >> 6;
+        auto row4 = [&](int t) -> f32x4 {
+          return *reinterpret_cast<const f32x4*>(scratch + t * 128 + ((rchunk ^ (t & 7)) << 4));
+        };
+        auto groups_sum = [&](f32x4 v) -> f32x4 {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] += __shfl_xor(v[i], 8, 64);
+            v[i] += __shfl_xor(v[i], 16, 64);
+            v[i] += __shfl_xor(v[i], 32, 64);
+          }
+          return v;
+        };
+        int r = 0;
+        while (r < 64) {
+          const int b = __builtin_amdgcn_readlane(my_utt, r);
+          int re = r + 1;
+          while (re < 64 && __builtin_amdgcn_readlane(my_utt, re) == b) ++re;
+          if (b >= 0) {
+            f32x4 s1 = z;
+            for (int t0 = r & ~7; t0 < re; t0 += 8) {
+              const int t = t0 + rrow;
+              if (t >= r && t < re) s1 += row4(t);
+            }
+            s1 = groups_sum(s1);
+            const f32x4 mu = s1 / (float)(re - r);
+            f32x4 m2 = z;
+            for (int t0 = r & ~7; t0 < re; t0 += 8) {
+              const int t = t0 + rrow;
+              if (t >= r && t < re) {
+                const f32x4 d = row4(t) - mu;
+                m2 += d * d;
+              }
+            }
+            m2 = groups_sum(m2);
+            if (nok && rrow == 0) {
+              const int64_t slot = (int64_t)p.pool_slotbase[b] + tile64;
+              *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2) * p.N + n) = s1;
+              *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2 + 1) * p.N + n) = m2;
+            }
+          }
+          r = re;
+        }
+      }
+      wave_lds_sync();
+    }
+  }
+}
+
+// Epilogue entry for the 128x32 wave tile.
+template <int ROWS>
+__device__ __forceinline__ void store_wave_tile_n32(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
+                                                    int lane, int wave, char* lds);
+
 // true when the vectorised LDS-staged epilogue applies to this launch
 __device__ __forceinline__ bool wide_epilogue_ok(const GemmArgs& p) {
   return (p.N & 3) == 0 && (!p.Y || ((p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0)) &&
@@ -329,6 +524,22 @@ __device__ __forceinline__ void store_wave_tile(const GemmArgs& p, const f32x16 
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) store_tile_scalar(p, acc[ni][mi], mbase + mi * 32, nbase + ni * 32, lane);
+}
+
+template <int ROWS>
+__device__ __forceinline__ void store_wave_tile_n32(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
+                                                    int lane, int wave, char* lds) {
+  if (wide_epilogue_ok(p)) {
+    if (p.act == ACT_RELU)
+      store_wave_tile_n32_impl<ACT_RELU, ROWS>(p, acc, mbase, nbase, lane, wave, lds);
+    else if (p.act == ACT_NONE)
+      store_wave_tile_n32_impl<ACT_NONE, ROWS>(p, acc, mbase, nbase, lane, wave, lds);
+    else
+      store_wave_tile_n32_impl<-1, ROWS>(p, acc, mbase, nbase, lane, wave, lds);
+    return;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) store_tile_scalar(p, acc[mi], mbase + mi * 32, nbase, lane);
 }
 
 }  // namespace xv
