@@ -1,16 +1,26 @@
-# Collect the round's evidence on the GPU box: bench lines (default bf16x3 + exact f32), rocprofv3
-# kernel trace/stats of the same command, PMC passes (separate runs, kernel-trace only).
-set -x
+# Collect the round's evidence on the GPU box: bench lines (default bf16x3 + exact f32 + the other configs),
+# rocprofv3 kernel trace/stats of the same command, PMC passes (separate runs, kernel-trace only).
+# usage: bash tools/profile_round.sh <tag>    -> gpurun_out/<tag>/
 tag=${1:-r01}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python bench.py > $out/bench_bf16x3.json 2> $out/bench_bf16x3.err
-python bench.py --precision f32 --cpu-seconds 0 > $out/bench_f32.json 2> $out/bench_f32.err
-python bench.py --pooling self_attention --cpu-seconds 0 > $out/bench_att_bf16x3.json 2> $out/bench_att.err
-python bench.py --varlen --cpu-seconds 0 > $out/bench_varlen_bf16x3.json 2> $out/bench_varlen.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --cpu-seconds 0 > $out/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -- python bench.py --cpu-seconds 0 --steps 3 --warmup 1 --no-profile > $out/pmc_sq.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py --cpu-seconds 0 --steps 3 --warmup 1 --no-profile > $out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py --cpu-seconds 0 --steps 3 --warmup 1 --no-profile > $out/pmc_write.log 2>&1
-ls -R $out | head -40
+step() { echo "$(date +%T) $*" >> $out/progress.txt; }
+step bench; python bench.py > $out/bench_bf16x3.json 2> $out/bench_bf16x3.err
+step f32; python bench.py --precision f32 --cpu-seconds 0 > $out/bench_f32.json 2> $out/bench_f32.err
+step att; python bench.py --pooling self_attention --cpu-seconds 0 > $out/bench_att_bf16x3.json 2> $out/bench_att.err
+step varlen; python bench.py --varlen --cpu-seconds 0 > $out/bench_varlen_bf16x3.json 2> $out/bench_varlen.err
+step etdnn; python bench.py --network extended_tdnn --cpu-seconds 0 > $out/bench_etdnn_bf16x3.json 2> $out/bench_etdnn.err
+step resnet; python bench.py --network resnet_18 --batch 64 --dim 40 --cpu-seconds 4 > $out/bench_resnet18_bf16x3.json 2> $out/bench_resnet.err
+step trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --cpu-seconds 0 > $out/trace.log 2>&1
+step pmc_sq; timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -- python bench.py --cpu-seconds 0 --steps 3 --warmup 1 --no-profile > $out/pmc_sq.log 2>&1
+step pmc_fetch; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py --cpu-seconds 0 --steps 3 --warmup 1 --no-profile > $out/pmc_fetch.log 2>&1
+step pmc_write; timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py --cpu-seconds 0 --steps 3 --warmup 1 --no-profile > $out/pmc_write.log 2>&1
+step summarise
+python profiles/summarize_trace.py $(find $out/trace -name "*kernel_trace.csv" | head -1) > $out/per_layer_summary.txt 2>&1
+cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+for c in sq fetch write; do python profiles/summarize_pmc.py $(find $out/pmc_$c -name "*counter_collection.csv" | head -1) > $out/pmc_${c}_summary.txt 2>&1; done
+rocm-smi --showproductname > $out/device.txt 2>&1
+rm -rf $out/trace $out/pmc_sq $out/pmc_fetch $out/pmc_write
+step done
+cat $out/progress.txt; head -c 600 $out/bench_bf16x3.json
