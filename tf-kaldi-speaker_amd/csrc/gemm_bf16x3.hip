@@ -742,6 +742,149 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14_kernel(GemmArgs p, int
   w14_tile<NPS>(p, mt * BM, nt * BN, w, smem3);
 }
 
+// ------------------------------------------------------------------------------------------
+// The 1 x 4 kernel with the weight fragments prefetched TWO steps ahead (three register buffers of 4 fragments).
+// With one step of lead a workgroup alone on a CU is bound by the load->use latency (~0.9 us per step against
+// 0.4 us of MFMA work), so only three resident workgroups together cover the matrix pipe and every prologue,
+// epilogue and the tail of the launch leave it under-fed; with two steps of lead two workgroups suffice.
+//   VMEM order per step:  D x NPS (top) , a0 (group 0) a1 (group 2) a2 (group 4) a3 (group 6)   [for step s+2]
+//   step s+2: before group 0 wait vmcnt(7+2*NPS) [a0,a1 of s] ; before group 4 vmcnt(7+2*NPS) [a2,a3 of s] ;
+//   slab switch vmcnt(4).
+// The activation fragment addresses use ONE swizzle and ONE row offset per lane ((32*mi + r) >> 1 == r >> 1 mod 8)
+// plus ds_read immediates, which frees the registers for the third weight buffer at 3 workgroups / CU.
+template <int NPS>
+__device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, int w, char* smem3) {
+  char* As = smem3;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+
+  const int ncb = (p.Kpad >> 5) / w;
+  const int nsteps = ncb * w;
+  const int ngroups = (BM + w - 1 + 7) >> 3;
+  const int lrow = lane >> 3, lpc = lane & 7;
+  const int64_t a_row_bytes = (p.a_pitch ? p.a_pitch : p.ldsbx) * 4;
+  const int kbt = p.a_pitch ? (p.ktap >> 5) : (p.Kpad >> 5);
+  const int64_t tap_bytes = p.a_pitch ? p.tap_stride * 4 : 0;
+  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(m0 + lrow) * a_row_bytes;
+  const int64_t nkb4k = (int64_t)(p.Kpad >> 5) * 4096;
+  const char* Wg = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((n0 >> 5) + wave) * nkb4k + lane * 16;
+  const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr_t)As;
+
+  auto dma_a = [&](int64_t koff, int buf, int g) {
+    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
+    const char* src = Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * DA_BYTES + g * 1024);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  // (cb, j) of the current step, of the next one and of the one after
+  int cb = 0, j = 0, cb1 = 0, j1 = 1, cb2, j2;
+  if (j1 == w) { j1 = 0; cb1 = 1; }
+  cb2 = cb1; j2 = j1 + 1;
+  if (j2 == w) { j2 = 0; cb2 = cb1 + 1; }
+
+  auto stamp = [&](int i) {
+#ifdef XV_GEMM_TRACE
+    if (p.trace && tid == 0) p.trace[(int64_t)blockIdx.x * 4 + i] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  };
+  stamp(0);
+  bf16x8 W0[4], W1[4], W2[4];            // [plane * 2 + ks]; W0: step 0, W1: step 1
+  {
+    const char* q1 = Wg + (int64_t)(1 < nsteps ? j1 * ncb + cb1 : 0) * 4096;
+    XV_GLD(W0[0], Wg, 0); XV_GLD(W0[1], Wg, 1024); XV_GLD(W0[2], Wg, 2048); XV_GLD(W0[3], Wg, 3072);
+    XV_GLD(W1[0], q1, 0); XV_GLD(W1[1], q1, 1024); XV_GLD(W1[2], q1, 2048); XV_GLD(W1[3], q1, 3072);
+  }
+  for (int g = wave; g < ngroups; g += 4) dma_a(0, 0, g);
+  int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : 128;
+  int blk_next = (kbt == 1 && p.a_pitch) ? 0 : 1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  stamp(1);
+  auto step = [&](int s, bf16x8 (&Wc)[4], bf16x8 (&Wn)[4]) __attribute__((always_inline)) {
+    const int kbn = s + 2 < nsteps ? j2 * ncb + cb2 : 0;        // weights of step s + 2 (unconditional issue)
+    const char* q = Wg + (int64_t)kbn * 4096;
+    const char* ab = As + (cb & 1) * DA_BYTES + (r32 + j) * DROW;
+    const int aswz = ((r32 + j) >> 1) & 7;
+    int off[4];                          // [ks * 2 + plane]: this lane's chunk of the swizzled 128-byte row
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      off[ks * 2] = ((ks * 2 + h) ^ aswz) << 4;
+      off[ks * 2 + 1] = ((4 + ks * 2 + h) ^ aswz) << 4;
+    }
+    bf16x8 fh[8], fl[8];                 // activation fragments of group g = ks * 4 + mi, read two groups ahead
+    auto read_frag = [&](int g) {
+      const int ks = g >> 2, mi = g & 3;
+      fh[g] = *reinterpret_cast<const bf16x8*>(ab + off[ks * 2] + mi * (32 * DROW));
+      fl[g] = *reinterpret_cast<const bf16x8*>(ab + off[ks * 2 + 1] + mi * (32 * DROW));
+    };
+    read_frag(0);
+    read_frag(1);
+    {
+      const int64_t ksrc = cb + 1 < ncb ? koff_next : 0;
+#pragma unroll
+      for (int i = 0; i < NPS; ++i) dma_a(ksrc, (cb + 1) & 1, min((j * NPS + i) * 4 + wave, ngroups - 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g == 0) XV_GLD(Wn[0], q, 0);        // hi ks0
+      if (g == 2) XV_GLD(Wn[2], q, 2048);     // lo ks0
+      if (g == 4) XV_GLD(Wn[1], q, 1024);     // hi ks1
+      if (g == 6) XV_GLD(Wn[3], q, 3072);     // lo ks1
+      if (g + 2 < 8) read_frag(g + 2);
+      if (g == 0) XV_WAIT2(7 + 2 * NPS, Wc[0], Wc[2]);
+      if (g == 4) XV_WAIT2(7 + 2 * NPS, Wc[1], Wc[3]);
+      const int ks = g >> 2, mi = g & 3;
+      const bf16x8 wh = Wc[ks], wl = Wc[2 + ks];
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, fl[g], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, fh[g], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, fh[g], acc[mi], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (cb1 != cb) {                     // slab switch
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __syncthreads();
+      if (++blk_next == kbt) {
+        blk_next = 0;
+        koff_next += tap_bytes - (int64_t)(kbt - 1) * 128;
+      } else {
+        koff_next += 128;
+      }
+    }
+    cb = cb1; j = j1;
+    cb1 = cb2; j1 = j2;
+    if (++j2 == w) { j2 = 0; ++cb2; }
+  };
+  for (int s = 0; s < nsteps; s += 3) {
+    step(s, W0, W2);
+    if (s + 1 < nsteps) step(s + 1, W1, W0);
+    if (s + 2 < nsteps) step(s + 2, W2, W1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  stamp(2);
+  store_wave_tile_n32<64>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
+  stamp(3);
+}
+
+template <int NPS>
+__global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_kernel(GemmArgs p, int nMt, int nNt, int w) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
+  const int mt = tile / nNt, nt = tile - mt * nNt;
+  w14p2_tile<NPS>(p, mt * BM, nt * BN, w, smem3);
+}
+
 #undef XV_GLD
 #undef XV_WAIT2
 
@@ -938,7 +1081,7 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
       if (g_trace && wgs <= kTraceWgs) { a.trace = g_trace; g_trace_wgs = wgs; }
     }
   }
-  static int force = -1;        // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA 128x128 | 2 weights-in-registers 2x2 waves, compiler waits | 3 the same with counted waits | 256 pipelined 256x128; 0 = default (weights in registers, 1x4 waves, counted waits)
+  static int force = -1;        // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA 128x128 | 2 weights-in-registers 2x2 waves, compiler waits | 3 the same with counted waits | 4 1x4 waves, one step ahead | 256 pipelined 256x128; 0 = default (1x4 waves, weights in registers two steps ahead)
   static bool attr_set = false;
   static int diag = 0;              // XVEC_GEMM_DIAG: timing-only ablation switches (outputs invalid)
   const size_t smem128 = (size_t)4 * TILE_B;
@@ -962,6 +1105,12 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
                          reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<4, 32>),
                          reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<1, 64>),
                          reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<4, 64>)};
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+    if (r != hipSuccess) return r;
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+    if (r != hipSuccess) return r;
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14_kernel<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
     if (r != hipSuccess) return r;
@@ -988,7 +1137,15 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
     hipLaunchKernelGGL(gemm_bf16x3_pipe_kernel, dim3(nMt * nNt), dim3(PNT), smempipe, s, a, nMt, nNt, w);
     return hipGetLastError();
   }
-  if (force != 1 && force != 2 && force != 3 && force != 128 && taps_ok) {   // default: 1 x 4 wave layout, weights in registers
+  if (force != 1 && force != 2 && force != 3 && force != 4 && force != 128 && taps_ok) {   // default: 1 x 4 waves, weights in registers two steps ahead
+    const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
+    const dim3 grid(nMt * nNt), block(256);
+    if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
+    if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1>), grid, block, smemw32, s, a, nMt, nNt, w);
+    else        hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4>), grid, block, smemw32, s, a, nMt, nNt, w);
+    return hipGetLastError();
+  }
+  if (force == 4 && taps_ok) {                   // A/B: 1 x 4 wave layout, weights one step ahead
     const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
     const dim3 grid(nMt * nNt), block(256);
     if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14_kernel<1>), grid, block, smemw32, s, a, nMt, nNt, w);
