@@ -15,9 +15,15 @@
 //     lane-half q&1 -- one ds_read_b128 per fragment, no repacking anywhere,
 //   * a temporal convolution stays an "overlapping-row" GEMM: row m of A is the contiguous
 //     run of w*cin/32 blocks that starts at frame m.
-// LDS rows are padded to 144 bytes: every ds_read_b128 lane group touches 16 distinct 16-byte
-// slots (conflict free).  Register-staged double buffering, one barrier per K step; 128x128
-// tile per 256-thread workgroup (2x2 waves of 64x64), two workgroups per CU.
+//
+// Three kernels, all on 128x128 workgroup tiles of 256 threads:
+//   gemm_bf16x3_w14p2_kernel  the default (section 3 below): activation slabs by LDS-DMA, weight fragments
+//                             straight into registers two steps ahead, one wave per 32-channel block, counted waits;
+//   gemm_bf16x3_dma_kernel    its predecessor, kept for A/B (XVEC_GEMM_TILE=1) and for the timing ablations
+//                             (XVEC_GEMM_DIAG): both operands by LDS-DMA, one barrier per K step;
+//   gemm_bf16x3_kernel        register-staged fallback for shapes the slab kernels do not take (more than 9 taps):
+//                             LDS rows padded to 144 bytes (conflict-free ds_read_b128), double buffering, one barrier
+//                             per K step, 2x2 waves of 64x64, two workgroups per CU.
 #include <cstdlib>
 
 #include "xv_epilogue.h"
@@ -132,9 +138,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs p, int nMt
 // tile and this step's share of the next slab, read 16 fragments, 24 MFMAs, __syncthreads()
 // (whose vmcnt(0) retires the DMA issued ~800 cycles earlier).
 namespace {
-#ifndef XV_WREG_LPG
-#define XV_WREG_LPG 1
-#endif
 constexpr int DROW = 128;                          // unpadded LDS row
 constexpr int DA_ROWS = 136;                       // 128 + (w-1 <= 7) halo rows, multiple of 8
 constexpr int DA_BYTES = DA_ROWS * DROW;
@@ -298,452 +301,37 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
 }
 
 // ------------------------------------------------------------------------------------------
-// 128x128 "weights in registers" kernel: the activation slab is staged exactly as in the DMA kernel, but
-// the weight fragments never touch LDS -- every lane loads its own 16-byte MFMA fragments of the packed
-// weight rows straight from L2/L1 (global_load_dwordx4, one step ahead, double-buffered in VGPRs).
-//  * 85 % of the LDS-DMA pieces of the kernel above were weight tiles; they and their landing wait go;
-//  * the only LDS hazard left is the slab, so the workgroup barrier drops from one per K step to one per
-//    channel block (every w steps);
-//  * the waits on the weight loads are per-register vmcnt(N) counts placed by the compiler, not vmcnt(0).
-//  * NPS = slab DMA pieces per wave per step (1 when w >= 5: 4w slots cover the <= 17 groups; 4 otherwise),
-//    fully unrolled: a variable-trip DMA loop makes the compiler fall back to vmcnt(0) everywhere.
-//  * EROWS = frames per epilogue pass: 32 -> 8 KB of scratch per wave, the workgroup needs only the 34 KB of
-//    the slabs and THREE workgroups share a CU (12 waves; 2288 tiles / 768 slots = 2.98 rounds instead of
-//    4.47 on 512); 64 -> 64 KB, two workgroups (the fused-pooling layer).
-//  * MI = 32-frame MFMA tiles per wave along M (2 -> the 128-frame workgroup tile).  MI = 1 half-height tiles for
-//    the last partial round of a launch were tried and gave nothing: a per-workgroup trace (tools/gemm_trace.py)
-//    shows that a workgroup alone on a CU is bound by the load->use latency of its weight fragments
-//    (~1.16 us per K step), not by its MFMA work, so halving the work of the stragglers does not shorten them.
-template <int NPS, int EROWS, int MI>
-__device__ __forceinline__ void wreg_tile(const GemmArgs& p, int m0, int n0, int w, int diag, char* smem3) {
-  constexpr int BMk = 64 * MI;           // frames per workgroup tile
-  char* As = smem3;                      // [2][DA_ROWS][128]; the rest of the allocation is epilogue scratch
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r32 = lane & 31, h = lane >> 5;
-
-  const int ncb = (p.Kpad >> 5) / w;
-  const int nsteps = ncb * w;
-  const int ngroups = (BMk + w - 1 + 7) >> 3;
-  const int lrow = lane >> 3, lpc = lane & 7;
-  const int64_t a_row_bytes = (p.a_pitch ? p.a_pitch : p.ldsbx) * 4, b_row_bytes = (int64_t)p.Kpad * 4;
-  const int kbt = p.a_pitch ? (p.ktap >> 5) : (p.Kpad >> 5);
-  const int64_t tap_bytes = p.a_pitch ? p.tap_stride * 4 : 0;
-  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(m0 + lrow) * a_row_bytes;
-  // fragment-major weights: 32-row block nb, K block kb, c = plane*2 + ks -> 64 lanes x 16 B contiguous
-  const int64_t nkb4k = (int64_t)(p.Kpad >> 5) * 4096;
-  const char* Wg0 = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((n0 + wn * 64) >> 5) * nkb4k + lane * 16;
-  const char* Wg1 = Wg0 + nkb4k;
-
-  auto dma_a = [&](int64_t koff, int buf, int g) {
-    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
-    __builtin_amdgcn_global_load_lds((gptr_t)(Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16),
-                                     (lptr_t)(As + buf * DA_BYTES + g * 1024), 16, 0, 0);
-  };
-  // W[nj*4 + plane*2 + ks]
-  auto load_w = [&](bf16x8 (&W)[8], int kb) {
-    const char* q0 = Wg0 + (int64_t)kb * 4096;
-    const char* q1 = Wg1 + (int64_t)kb * 4096;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      W[c] = *reinterpret_cast<const bf16x8*>(q0 + c * 1024);
-      W[4 + c] = *reinterpret_cast<const bf16x8*>(q1 + c * 1024);
-    }
-  };
-
-  f32x16 acc[2][MI];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < MI; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  auto stamp = [&](int i) {            // debug trace (build with -DXV_GEMM_TRACE, run with XVEC_TRACE_K): 100 MHz stamps
-#ifdef XV_GEMM_TRACE
-    if (p.trace && tid == 0) p.trace[(int64_t)blockIdx.x * 4 + i] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
-  };
-  stamp(0);
-  bf16x8 W0[8], W1[8];
-  load_w(W0, 0);
-  for (int g = wave; g < ngroups; g += 4) dma_a(0, 0, g);
-  int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : 128;
-  int blk_next = (kbt == 1 && p.a_pitch) ? 0 : 1;
-  __syncthreads();
-
-  stamp(1);
-  int cb = 0, j = 0;
-  auto step = [&](int s, bf16x8 (&Wc)[8], bf16x8 (&Wn)[8]) __attribute__((always_inline)) {
-    int cb_next = cb, j_next = j + 1;
-    if (j_next == w) { j_next = 0; cb_next = cb + 1; }
-    // Everything issued one step ago (this step's weights, slab pieces) must have landed; saying so HERE, before
-    // the new loads are issued, keeps the compiler from placing a vmcnt(0) after them (it cannot order
-    // LDS-DMA against register loads in the counter and would wait for the loads it has just issued).
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
-    // Issue is UNCONDITIONAL (clamped duplicates instead of branches): the compiler's vmcnt(N) for the
-    // weight registers must hold on every path, and a path that skips the issue forces vmcnt(0).
-    // Issue order is written out by hand and pinned with sched_barrier: the 8 weight loads and the slab piece are
-    // spread between the MFMAs (one per 3 MFMAs), not issued as a burst -- a burst from all 8 waves of the CU
-    // queues up in the texture-address unit and the in-order waves stop feeding the matrix pipe meanwhile.
-    const int kbn = (s + 1 < nsteps && !(diag & 32)) ? j_next * ncb + cb_next : 0;
-    const char* q0 = Wg0 + (int64_t)kbn * 4096;
-    const char* q1 = Wg1 + (int64_t)kbn * 4096;
-    const char* ab = As + (cb & 1) * DA_BYTES;
-    int aoff[MI], aswz[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int ra = wm * (32 * MI) + mi * 32 + r32 + j;
-      aoff[mi] = ra * DROW;
-      aswz[mi] = (ra >> 1) & 7;
-    }
-    bf16x8 ah[2][MI], al[2][MI];         // [ks][mi]
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      ah[0][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + ((h ^ aswz[mi]) << 4));
-      al[0][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((4 + h) ^ aswz[mi]) << 4));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (!(diag & 4)) {
-        // XV_WREG_LPG weight loads per group: 1 = spread over the whole step, 2 / 4 = first half / quarter
-        constexpr int lpg = XV_WREG_LPG;
-#pragma unroll
-        for (int l = 0; l < lpg; ++l) {
-          const int gi = g * lpg + l;
-          if (gi < 8) Wn[gi] = *reinterpret_cast<const bf16x8*>((gi < 4 ? q0 : q1) + (gi & 3) * 1024);
-        }
-      }
-      if (g < 2 * MI) {                  // ks = 1 fragments trickle in behind the ks = 0 MFMAs
-        const int mi = g >> 1;
-        if (g & 1) al[1][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((6 + h) ^ aswz[mi]) << 4));
-        else       ah[1][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((2 + h) ^ aswz[mi]) << 4));
-      }
-#pragma unroll
-      for (int t = g * (12 * MI) / 8; t < (g + 1) * (12 * MI) / 8; ++t) {   // 3 (MI = 2) or 1-2 (MI = 1) MFMAs per group
-        const int ks = t / (6 * MI), rem = t % (6 * MI), mi = rem / 6, nj = (rem / 3) & 1, term = rem % 3;
-        const bf16x8 wh = Wc[nj * 4 + ks], wl = Wc[nj * 4 + 2 + ks];
-        if (term == 0) acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al[ks][mi], acc[nj][mi], 0, 0, 0);
-        if (term == 1) acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah[ks][mi], acc[nj][mi], 0, 0, 0);
-        if (term == 2) acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah[ks][mi], acc[nj][mi], 0, 0, 0);
-      }
-      if (g == 3 && !(diag & 8)) {       // slab piece(s) of the next channel block, mid-step
-        const int64_t ksrc = cb + 1 < ncb ? koff_next : 0;    // last block: harmless re-stage into the idle buffer
-#pragma unroll
-        for (int i = 0; i < NPS; ++i) dma_a(ksrc, (cb + 1) & 1, min((j * NPS + i) * 4 + wave, ngroups - 1));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (cb_next != cb) {                 // slab switch: the only LDS hand-over
-      if (!(diag & 16)) __syncthreads();
-      if (++blk_next == kbt) {
-        blk_next = 0;
-        koff_next += tap_bytes - (int64_t)(kbt - 1) * 128;
-      } else {
-        koff_next += 128;
-      }
-    }
-    cb = cb_next;
-    j = j_next;
-  };
-  for (int s = 0; s < nsteps; s += 2) {
-    step(s, W0, W1);
-    if (s + 1 < nsteps) step(s + 1, W1, W0);
-  }
-  if (diag & 2) {       // diag bit1: skip the epilogue stores (timing only)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int nj = 0; nj < 2; ++nj) asm volatile("" ::"v"(acc[nj][mi]));
-    return;
-  }
-  stamp(2);
-  store_wave_tile<EROWS, MI>(p, acc, m0 + wm * (32 * MI), n0 + wn * 64, lane, wave, smem3);
-  stamp(3);
-}
-
-// ------------------------------------------------------------------------------------------
-// Same tile, same data movement, but every vector-memory instruction of the K loop is inline assembly and
-// every wait is an explicit s_waitcnt vmcnt(N) with an exact count.  The compiler-scheduled form above has to
-// drain the counter (vmcnt(0)) at the top of every step, so the weight fragment loaded LAST in step s has an
-// eighth of a step to land and a workgroup cannot go faster than ~1.16 us per step (tools/gemm_trace.py); three
-// such workgroups barely cover the matrix pipe.  Here fragment k of step s+1 is loaded in MFMA group k of step
-// s and first used in group k' of step s+1 -- in issue order, so each load has a whole step to land:
-//   VMEM order per step:  D x NPS (slab pieces, group 0) , a0 .. a7 (one per group)
-//   a0,a1 = (nj0; hi,lo; ks0)  a2,a3 = (nj1; ks0)  a4,a5 = (nj0; ks1)  a6,a7 = (nj1; ks1)
-//   step s+1: before group 0 wait vmcnt(7+NPS) [a0,a1] ; group 1 vmcnt(6+NPS) [a2,a3] ;
-//             group 4 vmcnt(7+NPS) [a4,a5] ; group 5 vmcnt(6+NPS) [a6,a7] ; slab switch vmcnt(8) [all D].
-// The counts rely on LDS-DMA loads and register loads retiring in issue order under the one counter
-// (checked on hardware: tools/vmcnt_order_test.hip, 0 violations in 2.6e8 trials).  The waits name the registers
-// they release as "+v" operands, so the compiler cannot move an MFMA above its wait.
+// Default kernel: 128x128 workgroup tile, "weights in registers", 1 x 4 wave layout, counted waits.
+//
+// How it got here (each step measured on MI355X, profiles/README.md; the intermediate kernels are in the git
+// history: 3fd7543 weights in registers 2 x 2 waves, 659ee67 counted waits, c74e274 1 x 4 waves):
+//  * the activation slab is staged exactly as in the LDS-DMA kernel above, but the weight fragments never touch
+//    LDS: they are packed a second time in MFMA-fragment-major order (one global_load_dwordx4 of a wave = 1 KB
+//    contiguous; reading the row-major SB rows directly touches 32 lines per instruction and is 60 % slower) and
+//    every lane loads its own fragments straight from L2 into VGPR buffers.  85 % of the LDS-DMA pieces of the
+//    kernel above were weight tiles; they and their landing wait go, and the only LDS hazard left is the slab,
+//    so the workgroup barrier drops from one per K step to one per channel block (every w steps);
+//  * the epilogue scratch is 8 KB per wave (64 frames x 128 B per pass), the workgroup needs only the 34 KB of
+//    the slabs, and THREE workgroups share a CU (12 waves);
+//  * every wave owns ONE 32-channel block and all 128 frames of the tile.  With 2 x 2 waves the two waves of a
+//    pair load identical weight fragments; the L1 counters showed the second request landing on a line still in
+//    flight 36 % of all L1 cycles (TCP_PENDING_STALL_CYCLES, profiles/r01/pmc_tcp1_wreg.txt) and the texture
+//    addresser busy 62 % of the kernel.  Here every weight byte is requested once per workgroup (4 loads per
+//    wave and step); the price is that all four waves read the whole slab from LDS (16 ds_read_b128 per wave and
+//    step), which the LDS has room for (halving the LDS reads of the 2 x 2 kernel changed nothing);
+//  * every vector-memory instruction of the K loop is inline assembly, issued one per group of 3 MFMAs in the
+//    order the fragments are needed (a burst from all waves of the CU queues up in the texture addresser and the
+//    in-order waves stop feeding the matrix pipe: -4..7 %), and every wait is an explicit s_waitcnt vmcnt(N) with
+//    an exact count.  The compiler can only drain the counter (vmcnt(0)) when LDS-DMA and register loads are
+//    mixed, and it needs the issue to be unconditional (a path that skips a load forces vmcnt(0)), hence the
+//    clamped duplicate slab pieces instead of branches (NPS pieces per wave and step: 1 when w >= 5, else 4).
+//    The counts rely on LDS-DMA loads and register loads retiring in issue order under the one counter (checked
+//    on hardware: tools/vmcnt_order_test.hip, 0 violations in 2.6e8 trials).  The waits name the registers they
+//    release as "+v" operands, so the compiler cannot move an MFMA above its wait.
 #define XV_GLD(dst, ptr, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(dst) : "v"(ptr))
 #define XV_WAIT2(N, ra, rb) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra), "+v"(rb) : "n"(N))
 
-template <int NPS, int EROWS>
-__device__ __forceinline__ void wreg_tile_asm(const GemmArgs& p, int m0, int n0, int w, char* smem3) {
-  char* As = smem3;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r32 = lane & 31, h = lane >> 5;
-
-  const int ncb = (p.Kpad >> 5) / w;
-  const int nsteps = ncb * w;
-  const int ngroups = (BM + w - 1 + 7) >> 3;
-  const int lrow = lane >> 3, lpc = lane & 7;
-  const int64_t a_row_bytes = (p.a_pitch ? p.a_pitch : p.ldsbx) * 4;
-  const int kbt = p.a_pitch ? (p.ktap >> 5) : (p.Kpad >> 5);
-  const int64_t tap_bytes = p.a_pitch ? p.tap_stride * 4 : 0;
-  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(m0 + lrow) * a_row_bytes;
-  const int64_t nkb4k = (int64_t)(p.Kpad >> 5) * 4096;
-  const char* Wg0 = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((n0 + wn * 64) >> 5) * nkb4k + lane * 16;
-  const char* Wg1 = Wg0 + nkb4k;
-  const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr_t)As;
-
-  auto dma_a = [&](int64_t koff, int buf, int g) {      // slab group g (8 rows x 128 B) -> LDS, untracked by the compiler
-    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
-    const char* src = Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16;
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * DA_BYTES + g * 1024);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  auto stamp = [&](int i) {
-#ifdef XV_GEMM_TRACE
-    if (p.trace && tid == 0) p.trace[(int64_t)blockIdx.x * 4 + i] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
-  };
-  stamp(0);
-  bf16x8 W0[8], W1[8];
-  XV_GLD(W0[0], Wg0, 0); XV_GLD(W0[1], Wg0, 1024); XV_GLD(W0[2], Wg0, 2048); XV_GLD(W0[3], Wg0, 3072);
-  XV_GLD(W0[4], Wg1, 0); XV_GLD(W0[5], Wg1, 1024); XV_GLD(W0[6], Wg1, 2048); XV_GLD(W0[7], Wg1, 3072);
-  for (int g = wave; g < ngroups; g += 4) dma_a(0, 0, g);
-  int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : 128;
-  int blk_next = (kbt == 1 && p.a_pitch) ? 0 : 1;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  stamp(1);
-  int cb = 0, j = 0;
-  auto step = [&](int s, bf16x8 (&Wc)[8], bf16x8 (&Wn)[8]) __attribute__((always_inline)) {
-    int cb_next = cb, j_next = j + 1;
-    if (j_next == w) { j_next = 0; cb_next = cb + 1; }
-    const int kbn = s + 1 < nsteps ? j_next * ncb + cb_next : 0;     // unconditional issue (the counts are static)
-    const char* q0 = Wg0 + (int64_t)kbn * 4096;
-    const char* q1 = Wg1 + (int64_t)kbn * 4096;
-    const char* ab = As + (cb & 1) * DA_BYTES;
-    int aoff[2], aswz[2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int ra = wm * 64 + mi * 32 + r32 + j;
-      aoff[mi] = ra * DROW;
-      aswz[mi] = (ra >> 1) & 7;
-    }
-    bf16x8 ah[2][2], al[2][2];           // [ks][mi]
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      ah[0][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + ((h ^ aswz[mi]) << 4));
-      al[0][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((4 + h) ^ aswz[mi]) << 4));
-    }
-    {                                    // slab piece(s) of the next channel block: oldest VMEM of the step
-      const int64_t ksrc = cb + 1 < ncb ? koff_next : 0;      // last block: harmless re-stage into the idle buffer
-#pragma unroll
-      for (int i = 0; i < NPS; ++i) dma_a(ksrc, (cb + 1) & 1, min((j * NPS + i) * 4 + wave, ngroups - 1));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      // a_g: fragment index f = nj*4 + plane*2 + ks in the order it is needed next step
-      if (g == 0) XV_GLD(Wn[0], q0, 0);
-      if (g == 1) XV_GLD(Wn[2], q0, 2048);
-      if (g == 2) XV_GLD(Wn[4], q1, 0);
-      if (g == 3) XV_GLD(Wn[6], q1, 2048);
-      if (g == 4) XV_GLD(Wn[1], q0, 1024);
-      if (g == 5) XV_GLD(Wn[3], q0, 3072);
-      if (g == 6) XV_GLD(Wn[5], q1, 1024);
-      if (g == 7) XV_GLD(Wn[7], q1, 3072);
-      if (g < 4) {                       // ks = 1 activation fragments trickle in behind the ks = 0 MFMAs
-        const int mi = g >> 1;
-        if (g & 1) al[1][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((6 + h) ^ aswz[mi]) << 4));
-        else       ah[1][mi] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((2 + h) ^ aswz[mi]) << 4));
-      }
-      if (g == 0) XV_WAIT2(7 + NPS, Wc[0], Wc[2]);
-      if (g == 1) XV_WAIT2(6 + NPS, Wc[4], Wc[6]);
-      if (g == 4) XV_WAIT2(7 + NPS, Wc[1], Wc[3]);
-      if (g == 5) XV_WAIT2(6 + NPS, Wc[5], Wc[7]);
-#pragma unroll
-      for (int t = 3 * g; t < 3 * g + 3; ++t) {
-        const int ks = t / 12, rem = t % 12, mi = rem / 6, nj = (rem / 3) & 1, term = rem % 3;
-        const bf16x8 wh = Wc[nj * 4 + ks], wl = Wc[nj * 4 + 2 + ks];
-        if (term == 0) acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al[ks][mi], acc[nj][mi], 0, 0, 0);
-        if (term == 1) acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah[ks][mi], acc[nj][mi], 0, 0, 0);
-        if (term == 2) acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah[ks][mi], acc[nj][mi], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (cb_next != cb) {                 // slab switch: every slab piece issued so far has landed (8 newer loads may fly)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      __syncthreads();
-      if (++blk_next == kbt) {
-        blk_next = 0;
-        koff_next += tap_bytes - (int64_t)(kbt - 1) * 128;
-      } else {
-        koff_next += 128;
-      }
-    }
-    cb = cb_next;
-    j = j_next;
-  };
-  for (int s = 0; s < nsteps; s += 2) {
-    step(s, W0, W1);
-    if (s + 1 < nsteps) step(s + 1, W1, W0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dummy loads of the last step still target W registers
-  __builtin_amdgcn_sched_barrier(0);
-  stamp(2);
-  store_wave_tile<EROWS, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, smem3);
-  stamp(3);
-}
-// ------------------------------------------------------------------------------------------
-// "1 x 4" wave layout of the same kernel: every wave owns ONE 32-channel block and all 128 frames of the tile.
-// In the 2 x 2 layout above the two waves of a pair load identical weight fragments; the L1 counters show the
-// second request landing on a line that is still in flight 36 % of all L1 cycles (TCP_PENDING_STALL_CYCLES,
-// profiles/r01/pmc_tcp1_wreg.txt) and the texture addresser busy 62 % of the kernel.  Here every weight byte is
-// requested exactly once per workgroup (4 loads per wave and step instead of 8); the price is that all four
-// waves read the whole activation slab from LDS (16 ds_read_b128 per wave and step instead of 8), which the LDS
-// has room for (halving the LDS reads of the 2 x 2 kernel changed nothing).
-//   VMEM order per step:  D x NPS (top) , a0 (group 0) a1 (group 2) a2 (group 4) a3 (group 6)
-//   a0,a1 = (hi,lo; ks0)  a2,a3 = (hi,lo; ks1);  group g = (ks, mi) = (g >> 2, g & 3), 3 MFMAs each
-//   step s+1: before group 0 wait vmcnt(3+NPS) [a0,a1] ; before group 4 vmcnt(3+NPS) [a2,a3] ; slab switch vmcnt(4).
-template <int NPS>
-__device__ __forceinline__ void w14_tile(const GemmArgs& p, int m0, int n0, int w, char* smem3) {
-  char* As = smem3;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r32 = lane & 31, h = lane >> 5;
-
-  const int ncb = (p.Kpad >> 5) / w;
-  const int nsteps = ncb * w;
-  const int ngroups = (BM + w - 1 + 7) >> 3;
-  const int lrow = lane >> 3, lpc = lane & 7;
-  const int64_t a_row_bytes = (p.a_pitch ? p.a_pitch : p.ldsbx) * 4;
-  const int kbt = p.a_pitch ? (p.ktap >> 5) : (p.Kpad >> 5);
-  const int64_t tap_bytes = p.a_pitch ? p.tap_stride * 4 : 0;
-  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(m0 + lrow) * a_row_bytes;
-  const int64_t nkb4k = (int64_t)(p.Kpad >> 5) * 4096;
-  const char* Wg = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((n0 >> 5) + wave) * nkb4k + lane * 16;
-  const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr_t)As;
-
-  auto dma_a = [&](int64_t koff, int buf, int g) {
-    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
-    const char* src = Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16;
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * DA_BYTES + g * 1024);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
-  };
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-  bf16x8 W0[4], W1[4];                   // [plane * 2 + ks]
-  XV_GLD(W0[0], Wg, 0); XV_GLD(W0[1], Wg, 1024); XV_GLD(W0[2], Wg, 2048); XV_GLD(W0[3], Wg, 3072);
-  for (int g = wave; g < ngroups; g += 4) dma_a(0, 0, g);
-  int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : 128;
-  int blk_next = (kbt == 1 && p.a_pitch) ? 0 : 1;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  int cb = 0, j = 0;
-  auto step = [&](int s, bf16x8 (&Wc)[4], bf16x8 (&Wn)[4]) __attribute__((always_inline)) {
-    int cb_next = cb, j_next = j + 1;
-    if (j_next == w) { j_next = 0; cb_next = cb + 1; }
-    const int kbn = s + 1 < nsteps ? j_next * ncb + cb_next : 0;
-    const char* q = Wg + (int64_t)kbn * 4096;
-    const char* ab = As + (cb & 1) * DA_BYTES;
-    int aoff[4], aswz[4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int ra = mi * 32 + r32 + j;
-      aoff[mi] = ra * DROW;
-      aswz[mi] = (ra >> 1) & 7;
-    }
-    bf16x8 fh[8], fl[8];                 // activation fragments of group g = ks * 4 + mi, read two groups ahead
-    auto read_frag = [&](int g) {
-      const int ks = g >> 2, mi = g & 3;
-      fh[g] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((ks * 2 + h) ^ aswz[mi]) << 4));
-      fl[g] = *reinterpret_cast<const bf16x8*>(ab + aoff[mi] + (((4 + ks * 2 + h) ^ aswz[mi]) << 4));
-    };
-    read_frag(0);
-    read_frag(1);
-    {
-      const int64_t ksrc = cb + 1 < ncb ? koff_next : 0;
-#pragma unroll
-      for (int i = 0; i < NPS; ++i) dma_a(ksrc, (cb + 1) & 1, min((j * NPS + i) * 4 + wave, ngroups - 1));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (g == 0) XV_GLD(Wn[0], q, 0);        // hi ks0
-      if (g == 2) XV_GLD(Wn[2], q, 2048);     // lo ks0
-      if (g == 4) XV_GLD(Wn[1], q, 1024);     // hi ks1
-      if (g == 6) XV_GLD(Wn[3], q, 3072);     // lo ks1
-      if (g + 2 < 8) read_frag(g + 2);
-      if (g == 0) XV_WAIT2(3 + NPS, Wc[0], Wc[2]);
-      if (g == 4) XV_WAIT2(3 + NPS, Wc[1], Wc[3]);
-      const int ks = g >> 2, mi = g & 3;
-      const bf16x8 wh = Wc[ks], wl = Wc[2 + ks];
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, fl[g], acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, fh[g], acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, fh[g], acc[mi], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (cb_next != cb) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      __syncthreads();
-      if (++blk_next == kbt) {
-        blk_next = 0;
-        koff_next += tap_bytes - (int64_t)(kbt - 1) * 128;
-      } else {
-        koff_next += 128;
-      }
-    }
-    cb = cb_next;
-    j = j_next;
-  };
-  for (int s = 0; s < nsteps; s += 2) {
-    step(s, W0, W1);
-    if (s + 1 < nsteps) step(s + 1, W1, W0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  store_wave_tile_n32<64>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
-}
-
-template <int NPS>
-__global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14_kernel(GemmArgs p, int nMt, int nNt, int w) {
-  extern __shared__ __attribute__((aligned(16))) char smem3[];
-  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
-  const int mt = tile / nNt, nt = tile - mt * nNt;
-  w14_tile<NPS>(p, mt * BM, nt * BN, w, smem3);
-}
-
-// ------------------------------------------------------------------------------------------
-// The 1 x 4 kernel with the weight fragments prefetched TWO steps ahead (three register buffers of 4 fragments).
+//  * the weight fragments are prefetched TWO steps ahead (three register buffers of 4 fragments).
 // With one step of lead a workgroup alone on a CU is bound by the load->use latency (~0.9 us per step against
 // 0.4 us of MFMA work), so only three resident workgroups together cover the matrix pipe and every prologue,
 // epilogue and the tail of the launch leave it under-fed; with two steps of lead two workgroups suffice.
@@ -888,181 +476,6 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_kernel(GemmArgs p, i
 #undef XV_GLD
 #undef XV_WAIT2
 
-template <int NPS, int EROWS>
-__global__ __launch_bounds__(256, EROWS == 32 ? 3 : 2) void gemm_bf16x3_wasm_kernel(GemmArgs p, int nMt, int nNt, int w) {
-  extern __shared__ __attribute__((aligned(16))) char smem3[];
-  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
-  const int mt = tile / nNt, nt = tile - mt * nNt;
-  wreg_tile_asm<NPS, EROWS>(p, mt * BM, nt * BN, w, smem3);
-}
-
-template <int NPS, int EROWS>
-__global__ __launch_bounds__(256, EROWS == 32 ? 3 : 2) void gemm_bf16x3_wreg_kernel(GemmArgs p, int nMt, int nNt, int w, int diag) {
-  extern __shared__ __attribute__((aligned(16))) char smem3[];
-  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
-  const int mt = tile / nNt, nt = tile - mt * nNt;
-  wreg_tile<NPS, EROWS, 2>(p, mt * BM, nt * BN, w, diag, smem3);
-}
-
-// ------------------------------------------------------------------------------------------
-// 256x128 software-pipelined kernel (large M): 512 threads = 8 waves (4 along M x 2 along N) of
-// 64x64, one workgroup per CU.  Same DMA staging / swizzle / slab reuse as the kernel above, plus
-//  * half the weight traffic per FLOP (each 128x32 weight tile feeds 256 frames);
-//  * a 3-deep LDS ring for the weight tiles (and for the slab when w == 1): the DMA for step s+2
-//    is issued in step s, so a tile has a whole step to land before anyone reads it;
-//  * register double-buffered fragments: the 16 ds_read_b128 of step s+1 are issued BEFORE the
-//    24 MFMAs of step s, so the MFMA stream of a wave never waits on LDS.
-// Ablation on the 128x128 kernel (profiles/): ds_read + MFMA alone run at ~87 % of the clock-
-// adjusted MFMA peak; DMA traffic costs 24 % and the barrier 4 % of the loop.
-namespace {
-constexpr int PBM = 256, PNT = 512;
-constexpr int PA_ROWS = PBM + 8;                   // slab rows incl. w-1 <= 7 halo rows
-constexpr int PA_BYTES = PA_ROWS * DROW;           // 33792
-constexpr int PB_BYTES = BN * DROW;                // 16384
-struct Frags { bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2]; };   // [k16 step][tile]
-}  // namespace
-
-__global__ __launch_bounds__(512, 2) void gemm_bf16x3_pipe_kernel(GemmArgs p, int nMt, int nNt, int w) {
-  extern __shared__ __attribute__((aligned(16))) char smem3[];
-  char* As = smem3;                      // [3][PA_ROWS][128]
-  char* Bs = smem3 + 3 * PA_BYTES;       // [3][BN][128]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r32 = lane & 31, h = lane >> 5;
-
-  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
-  const int mt = tile / nNt, nt = tile - mt * nNt;
-  const int m0 = mt * PBM, n0 = nt * BN;
-
-  const int ncb = (p.Kpad >> 5) / w;               // channel blocks per frame
-  const int nsteps = ncb * w;
-  const int ngroups = (PBM + w - 1 + 7) >> 3;       // 8-row DMA groups per slab (32 or 33)
-  const int aring = (w == 1) ? 3 : 2;               // slab ring depth
-  const int gps = (w == 1) ? ngroups : (ngroups + w - 2) / (w - 1);   // slab groups issued per step
-  const int lrow = lane >> 3, lpc = lane & 7;
-  const int64_t a_row_bytes = p.ldsbx * 4, b_row_bytes = (int64_t)p.Kpad * 4;
-  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + (int64_t)(m0 + lrow) * a_row_bytes;
-  const char* Bg = reinterpret_cast<const char*>(p.Wsb) + (int64_t)(n0 + lrow) * b_row_bytes;
-
-  auto dma_a = [&](int cb, int buf, int g) {
-    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
-    __builtin_amdgcn_global_load_lds((gptr_t)(Ag + (int64_t)(8 * g) * a_row_bytes + cb * 128 + c * 16),
-                                     (lptr_t)(As + buf * PA_BYTES + g * 1024), 16, 0, 0);
-  };
-  auto dma_b = [&](int kb, int buf, int g) {
-    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
-    __builtin_amdgcn_global_load_lds((gptr_t)(Bg + (int64_t)(8 * g) * b_row_bytes + (int64_t)kb * 128 + c * 16),
-                                     (lptr_t)(Bs + buf * PB_BYTES + g * 1024), 16, 0, 0);
-  };
-
-  // B fragment offsets (row fixed per lane): chunk c = plane*4 + ks*2 + h
-  int boff[2], bswz[2];
-#pragma unroll
-  for (int nj = 0; nj < 2; ++nj) {
-    const int rb = wn * 64 + nj * 32 + r32;
-    boff[nj] = rb * DROW;
-    bswz[nj] = (rb >> 1) & 7;
-  }
-  auto read_frags = [&](Frags& f, int abuf, int j, int bbuf) {
-    const char* ab = As + abuf * PA_BYTES;
-    const char* bb = Bs + bbuf * PB_BYTES;
-    int aoff[2], aswz[2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int ra = wm * 64 + mi * 32 + r32 + j;
-      aoff[mi] = ra * DROW;
-      aswz[mi] = (ra >> 1) & 7;
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ch = ks * 2 + h, cl = 4 + ks * 2 + h;
-        f.ah[ks][i] = *reinterpret_cast<const bf16x8*>(ab + aoff[i] + ((ch ^ aswz[i]) << 4));
-        f.al[ks][i] = *reinterpret_cast<const bf16x8*>(ab + aoff[i] + ((cl ^ aswz[i]) << 4));
-        f.bh[ks][i] = *reinterpret_cast<const bf16x8*>(bb + boff[i] + ((ch ^ bswz[i]) << 4));
-        f.bl[ks][i] = *reinterpret_cast<const bf16x8*>(bb + boff[i] + ((cl ^ bswz[i]) << 4));
-      }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  auto mfma24 = [&](const Frags& f) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-          acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[ks][nj], f.al[ks][mi], acc[nj][mi], 0, 0, 0);
-          acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bl[ks][nj], f.ah[ks][mi], acc[nj][mi], 0, 0, 0);
-          acc[nj][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.bh[ks][nj], f.ah[ks][mi], acc[nj][mi], 0, 0, 0);
-        }
-  };
-
-  // (cb, j) of steps s, s+1, s+2 and their ring slots, advanced incrementally
-  int cb0 = 0, j0 = 0, cb1 = 0, j1 = 1, cb2 = 0, j2 = 2;
-  auto norm = [&](int& cb, int& j) { while (j >= w) { j -= w; ++cb; } };
-  norm(cb1, j1);
-  norm(cb2, j2);
-  int b0 = 0, b1 = 1, b2 = 2;            // weight ring slots of steps s, s+1, s+2
-
-  // prologue: slab 0 (and slab 1 when w == 1), weight tiles of steps 0 and 1
-  for (int g = wave; g < ngroups; g += 8) dma_a(0, 0, g);
-  if (w == 1 && ncb > 1)
-    for (int g = wave; g < ngroups; g += 8) dma_a(1, 1, g);
-#pragma unroll
-  for (int q = 0; q < 2; ++q) dma_b(0, 0, wave + 8 * q);
-  if (nsteps > 1) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) dma_b(j1 * ncb + cb1, 1, wave + 8 * q);
-  }
-  __syncthreads();
-
-  Frags f0, f1;
-  read_frags(f0, 0, 0, 0);
-
-  auto body = [&](int s, const Frags& fc, Frags& fn) {
-    __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): fragments of step s are in registers
-    // DMA two steps ahead: weight tile of step s+2, and this step's share of the next slab
-    if (s + 2 < nsteps) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) dma_b(j2 * ncb + cb2, b2, wave + 8 * q);
-    }
-    if (w == 1) {
-      if (cb0 + 2 < ncb)
-        for (int g = wave; g < ngroups; g += 8) dma_a(cb0 + 2, (cb0 + 2) % 3, g);
-    } else if (cb0 + 1 < ncb && j0 < w - 1) {
-      const int gend = min((j0 + 1) * gps, ngroups);
-      for (int g = j0 * gps + wave; g < gend; g += 8) dma_a(cb0 + 1, (cb0 + 1) & 1, g);
-    }
-    // fragments of step s+1 (their tiles landed before the previous barrier)
-    if (s + 1 < nsteps) read_frags(fn, aring == 3 ? cb1 % 3 : (cb1 & 1), j1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma24(fc);
-    __syncthreads();
-    cb0 = cb1; j0 = j1; cb1 = cb2; j1 = j2;
-    ++j2; if (j2 == w) { j2 = 0; ++cb2; }
-    const int t = b0; b0 = b1; b1 = b2; b2 = t;
-  };
-
-  for (int s = 0; s < nsteps; s += 2) {
-    body(s, f0, f1);
-    if (s + 1 < nsteps) body(s + 1, f1, f0);
-  }
-
-  // the final barrier of the K loop has retired every LDS read: reuse the ring as store scratch
-  store_wave_tile(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, smem3);
-}
-
 namespace {
 long long* g_trace = nullptr;      // debug trace buffer (device), kTraceWgs workgroups x 4 stamps
 int g_trace_wgs = 0;
@@ -1081,13 +494,12 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
       if (g_trace && wgs <= kTraceWgs) { a.trace = g_trace; g_trace_wgs = wgs; }
     }
   }
-  static int force = -1;        // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA 128x128 | 2 weights-in-registers 2x2 waves, compiler waits | 3 the same with counted waits | 4 1x4 waves, one step ahead | 256 pipelined 256x128; 0 = default (1x4 waves, weights in registers two steps ahead)
+  static int force = -1;        // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA weights, barrier per step; 0 = default
   static bool attr_set = false;
-  static int diag = 0;              // XVEC_GEMM_DIAG: timing-only ablation switches (outputs invalid)
+  static int diag = 0;              // XVEC_GEMM_DIAG: timing-only ablation switches of the LDS-DMA kernel (outputs invalid)
   const size_t smem128 = (size_t)4 * TILE_B;
   const size_t smemdma = (size_t)2 * DA_BYTES + 2 * DB_BYTES;
-  const size_t smempipe = (size_t)3 * PA_BYTES + 3 * PB_BYTES;
-  const size_t smemw32 = (size_t)2 * DA_BYTES, smemw64 = 65536;   // slabs (>= 4 x 8 KB scratch) | 4 x 16 KB scratch
+  const size_t smemw32 = (size_t)2 * DA_BYTES;      // two slabs; the 4 x 8 KB epilogue scratch overlays them
   if (!attr_set) {
     const char* e = getenv("XVEC_GEMM_TILE");
     force = e ? atoi(e) : 0;
@@ -1097,34 +509,11 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemdma);
     if (r != hipSuccess) return r;
-    const void* wk[4] = {reinterpret_cast<const void*>(gemm_bf16x3_wreg_kernel<1, 32>),
-                         reinterpret_cast<const void*>(gemm_bf16x3_wreg_kernel<4, 32>),
-                         reinterpret_cast<const void*>(gemm_bf16x3_wreg_kernel<1, 64>),
-                         reinterpret_cast<const void*>(gemm_bf16x3_wreg_kernel<4, 64>)};
-    const void* wa[4] = {reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<1, 32>),
-                         reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<4, 32>),
-                         reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<1, 64>),
-                         reinterpret_cast<const void*>(gemm_bf16x3_wasm_kernel<4, 64>)};
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
     if (r != hipSuccess) return r;
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-    if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-    if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14_kernel<4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-    if (r != hipSuccess) return r;
-    for (int i = 0; i < 4; ++i) {
-      r = hipFuncSetAttribute(wk[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(i < 2 ? smemw32 : smemw64));
-      if (r != hipSuccess) return r;
-      r = hipFuncSetAttribute(wa[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)(i < 2 ? smemw32 : smemw64));
-      if (r != hipSuccess) return r;
-    }
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_pipe_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smempipe);
     if (r != hipSuccess) return r;
     const char* e3 = getenv("XVEC_GEMM_DIAG");
     diag = e3 ? atoi(e3) : 0;
@@ -1132,50 +521,12 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
   }
   const int w = a.K / a.cin > 0 && a.ldsbx == a.cin ? a.K / a.cin : 1;   // taps (dense: 1)
   const bool taps_ok = w <= 9 && (a.Kpad >> 5) % w == 0;   // slab halo: 128 + w - 1 <= DA_ROWS (136)
-  if (taps_ok && w <= 8 && force == 256) {   // A/B variant only: measured slower than the 128x128 DMA kernel (profiles/)
-    const int nMt = (a.M + PBM - 1) / PBM, nNt = a.Npad / BN;
-    hipLaunchKernelGGL(gemm_bf16x3_pipe_kernel, dim3(nMt * nNt), dim3(PNT), smempipe, s, a, nMt, nNt, w);
-    return hipGetLastError();
-  }
-  if (force != 1 && force != 2 && force != 3 && force != 4 && force != 128 && taps_ok) {   // default: 1 x 4 waves, weights in registers two steps ahead
+  if (force != 1 && force != 128 && taps_ok) {   // default: 1 x 4 waves, weights in registers two steps ahead
     const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
     const dim3 grid(nMt * nNt), block(256);
     if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
     if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1>), grid, block, smemw32, s, a, nMt, nNt, w);
     else        hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4>), grid, block, smemw32, s, a, nMt, nNt, w);
-    return hipGetLastError();
-  }
-  if (force == 4 && taps_ok) {                   // A/B: 1 x 4 wave layout, weights one step ahead
-    const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
-    const dim3 grid(nMt * nNt), block(256);
-    if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14_kernel<1>), grid, block, smemw32, s, a, nMt, nNt, w);
-    else        hipLaunchKernelGGL((gemm_bf16x3_w14_kernel<4>), grid, block, smemw32, s, a, nMt, nNt, w);
-    return hipGetLastError();
-  }
-  if (force == 3 && taps_ok) {                   // A/B: 2 x 2 wave layout, weights in registers, counted waits
-    const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
-    const dim3 grid(nMt * nNt), block(256);
-    if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
-    if (a.pool_part) {
-      if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_wasm_kernel<1, 64>), grid, block, smemw64, s, a, nMt, nNt, w);
-      else        hipLaunchKernelGGL((gemm_bf16x3_wasm_kernel<4, 64>), grid, block, smemw64, s, a, nMt, nNt, w);
-    } else {
-      if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_wasm_kernel<1, 32>), grid, block, smemw32, s, a, nMt, nNt, w);
-      else        hipLaunchKernelGGL((gemm_bf16x3_wasm_kernel<4, 32>), grid, block, smemw32, s, a, nMt, nNt, w);
-    }
-    return hipGetLastError();
-  }
-  if (force == 2 && taps_ok) {                   // A/B: the compiler-scheduled form of the same kernel
-    const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
-    const dim3 grid(nMt * nNt), block(256);
-    if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
-    if (a.pool_part) {                    // fused pooling needs the whole 64-frame tile staged: 2 workgroups / CU
-      if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_wreg_kernel<1, 64>), grid, block, smemw64, s, a, nMt, nNt, w, diag);
-      else        hipLaunchKernelGGL((gemm_bf16x3_wreg_kernel<4, 64>), grid, block, smemw64, s, a, nMt, nNt, w, diag);
-    } else {                              // 8 KB of epilogue scratch per wave: 3 workgroups / CU
-      if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_wreg_kernel<1, 32>), grid, block, smemw32, s, a, nMt, nNt, w, diag);
-      else        hipLaunchKernelGGL((gemm_bf16x3_wreg_kernel<4, 32>), grid, block, smemw32, s, a, nMt, nNt, w, diag);
-    }
     return hipGetLastError();
   }
   if (force != 128 && taps_ok) {
