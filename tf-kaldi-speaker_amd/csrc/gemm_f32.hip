@@ -29,7 +29,9 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDT = BK + 4;               // padded LDS row (floats)
 constexpr int TILE_F = BM * LDT;          // floats per operand tile
 
-template <bool ALIGNED>
+// FORM: 0 = any shape / alignment (scalar loads), 1 = aligned 1-D rows, 2 = aligned grid form (ResNet taps).  The grid
+// addressing is a template case of its own: as a run-time branch in the 1-D loader it cost the TDNN layers 12 %.
+template <int FORM>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, int nNt, int kper) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][BM][LDT]
@@ -68,10 +70,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int nMt, i
     for (int i = 0; i < 4; ++i) {
       const int row = lr + 32 * i;
       rb[i] = *reinterpret_cast<const f32x4*>(p.Wt + (int64_t)(n0 + row) * p.Kpad + k);
-      if (ALIGNED) {
+      if (FORM != 0) {
         if (k >= p.K) {
           ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else if (p.a_pitch) {        // grid form: A[m, tap*ktap + kk] = X[a_off + m*a_pitch + tap*tap_stride + kk]
+        } else if (FORM == 2) {        // grid form: A[m, tap*ktap + kk] = X[a_off + m*a_pitch + tap*tap_stride + kk]
           const int tap = k / p.ktap;
           ra[i] = *reinterpret_cast<const f32x4*>(p.X + p.a_off + (int64_t)(m0 + row) * p.a_pitch +
                                                   (int64_t)tap * p.tap_stride + (k - tap * p.ktap));
@@ -179,10 +181,13 @@ hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s) {
   const size_t smem = (size_t)4 * TILE_F * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<false>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<0>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -190,10 +195,12 @@ hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s) {
   GemmArgs b = a;
   b.ksplit = ks;
   dim3 grid(nMt * nNt * ks), block(256);
-  if (aligned)
-    hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, block, smem, s, b, nMt, nNt, kper);
+  if (aligned && a.a_pitch)
+    hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, block, smem, s, b, nMt, nNt, kper);
+  else if (aligned)
+    hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, block, smem, s, b, nMt, nNt, kper);
   else
-    hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, block, smem, s, b, nMt, nNt, kper);
+    hipLaunchKernelGGL(gemm_f32_kernel<0>, grid, block, smem, s, b, nMt, nNt, kper);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || ks == 1) return e;
   const int64_t total = (int64_t)a.M * a.N;
