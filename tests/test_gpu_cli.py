@@ -106,3 +106,38 @@ def test_extract_frame_and_attention_cli(tmp_path, repo_root):
         ref = ref_numpy.predict(u, weights, params, 30, node="attention_weights")
         assert att["u%d" % i].shape == ref.shape == (2, u.shape[0] - 14)
         assert np.linalg.norm(att["u%d" % i] - ref) / np.linalg.norm(ref) <= 1e-4
+
+
+def test_extract_angle_matches_oracle(tmp_path, repo_root):
+    """extract_angle.py surface: scp in, `key angle` lines out, angle to the speaker's softmax weight vector."""
+    from tf_kaldi_speaker_amd import extract_angle, kaldi_io, model_io, synth
+    params = dict(synth.TDNN_STAT_PARAMS, num_nodes_pooling_layer=160, num_nodes_last_layer=48)
+    weights = synth.synth_weights(params, 30, seed=5, channels=64)
+    rng = np.random.default_rng(1)
+    weights[model_io.SOFTMAX_KERNEL] = rng.standard_normal((48, 4)).astype(np.float32)
+    model_dir = str(tmp_path / "exp")
+    model_io.save_model(model_dir, params, 30, weights, step=10)
+    lens = [30, 24, 80, 120]
+    utts = synth.synth_features(len(lens), lens, 30, seed=2)
+    ark = str(tmp_path / "feats.ark")
+    with open(ark, "wb") as f, open(tmp_path / "feats.scp", "w") as scp, open(tmp_path / "utt2spk", "w") as u2s:
+        for i, u in enumerate(utts):
+            key = "utt%d" % i
+            f.write((key + " ").encode())
+            scp.write("%s %s:%d\n" % (key, ark, f.tell()))
+            kaldi_io.write_mat(f, u)
+            u2s.write("%s spk%d\n" % (key, i % 4))
+    with open(tmp_path / "spklist", "w") as f:
+        for i in range(4):
+            f.write("spk%d %d\n" % (i, i))
+    rc = extract_angle.main(["--chunk-size", "100", "--precision", "f32", model_dir, str(tmp_path / "feats.scp"),
+                             str(tmp_path / "utt2spk"), str(tmp_path / "spklist"), str(tmp_path / "angles")])
+    assert rc == 0
+    got = [l.split() for l in open(tmp_path / "angles")]
+    assert [g[0] for g in got] == ["utt0", "utt2", "utt3"]                 # T=24 < 25 skipped
+    cw = np.transpose(weights[model_io.SOFTMAX_KERNEL])
+    net = {k: v for k, v in weights.items() if k != model_io.SOFTMAX_KERNEL}
+    for (key, val), i in zip(got, [0, 2, 3]):
+        out = ref_numpy.predict(utts[i][:100], net, params, 30, node="output")
+        want = extract_angle.angle(cw[i % 4].astype(np.float64), out)
+        assert abs(float(val) - want) < 5e-5, (key, val, want)

@@ -170,3 +170,25 @@ def test_native_format_vectors_is_byte_identical(native):
     for k, x in zip(keys, v):
         kaldi_io.write_vec_flt(buf, x, key=k)
     assert native.format_vectors(keys, v) == buf.getvalue()
+
+
+def test_read_mat_scp_with_offsets(tmp_path):
+    """scp lines `key file:offset` (dataset/kaldi_io.py:953-972): offsets point at the byte after `key `."""
+    from tf_kaldi_speaker_amd import kaldi_io
+    rng = np.random.default_rng(3)
+    mats = {"uttA": rng.standard_normal((7, 5)).astype(np.float32), "uttB": rng.standard_normal((3, 5)).astype(np.float32)}
+    ark = str(tmp_path / "feats.ark")
+    offsets = {}
+    with open(ark, "wb") as f:
+        for k, m in mats.items():
+            f.write((k + " ").encode())
+            offsets[k] = f.tell()
+            kaldi_io.write_mat(f, m)
+    scp = str(tmp_path / "feats.scp")
+    with open(scp, "w") as f:
+        for k in mats:
+            f.write("%s %s:%d\n" % (k, ark, offsets[k]))
+    got = dict(kaldi_io.read_mat_scp(scp))
+    assert list(got) == list(mats)
+    for k in mats:
+        np.testing.assert_array_equal(got[k], mats[k])

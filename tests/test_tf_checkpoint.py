@@ -33,7 +33,8 @@ def test_bundle_round_trip_multi_block(tmp_path):
 
 
 def test_model_dir_with_tf_bundle(tmp_path):
-    """nnet/checkpoint -> model-<step>.index/.data: loaded without TF; slots and loss layer filtered out."""
+    """nnet/checkpoint -> model-<step>.index/.data: loaded without TF; optimizer slots filtered out, the softmax
+    kernel kept (extract_angle.py needs it; the predict graph ignores it)."""
     p = dict(synth.TDNN_STAT_PARAMS, num_nodes_pooling_layer=16)
     w = synth.synth_weights(p, 6, seed=2, channels=16)
     nnet = model_io.save_model(str(tmp_path / "exp"), p, 6, w, step=42)
@@ -41,9 +42,10 @@ def test_model_dir_with_tf_bundle(tmp_path):
     extra = dict(w)
     extra["tdnn/tdnn2_conv/bias/Momentum"] = np.zeros(16, np.float32)
     extra["softmax/output/kernel"] = np.ones((16, 3), np.float32)
+    extra["softmax/output/kernel/Momentum"] = np.ones((16, 3), np.float32)
     tf_checkpoint.write_bundle(os.path.join(nnet, "model-42"), extra)
     got, step = model_io.load_weights(nnet)
-    assert step == 42 and set(got) == set(w)
+    assert step == 42 and set(got) == set(w) | {model_io.SOFTMAX_KERNEL}
     for k in w:
         np.testing.assert_array_equal(got[k], w[k])
 

@@ -353,6 +353,22 @@ def read_mat_ark(file_or_fd):
             fd.close()
 
 
+def read_mat_scp(file_or_fd):
+    """Generator of (key, matrix) over a Kaldi scp: lines `key rxfile`, rxfile = `file` or `file:offset`
+    (dataset/kaldi_io.py:953-972)."""
+    fd = open_or_fd(file_or_fd)
+    try:
+        for line in fd:
+            line = line.decode() if isinstance(line, bytes) else line
+            if not line.strip():
+                continue
+            key, rxfile = line.strip().split(' ', 1)
+            yield key, read_mat(rxfile.strip())
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
 def write_mat(file_or_fd, m, key=''):
     """Write one binary Kaldi matrix record (dataset/kaldi_io.py:1175-1208)."""
     fd = open_or_fd(file_or_fd, mode='wb')

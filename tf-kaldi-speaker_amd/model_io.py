@@ -66,7 +66,16 @@ def load_weights(nnet_dir):
     return weights, step
 
 
+SOFTMAX_KERNEL = "softmax/output/kernel"    # [E, num_speakers]; only extract_angle.py reads it (extract_angle.py:64-67)
+
+
 def _graph_variable(name):
+    if name == SOFTMAX_KERNEL:
+        return True
+    return _network_variable(name)
+
+
+def _network_variable(name):
     """Variables of the predict graph live under the network scope; skip optimizer slots
     (".../Momentum", ".../Adam*"), the global step and the loss layer ("softmax/...")."""
     if not name.startswith(("tdnn/", "etdnn/", "resnet_18/")):
