@@ -25,6 +25,7 @@
 //                             LDS rows padded to 144 bytes (conflict-free ds_read_b128), double buffering, one barrier
 //                             per K step, 2x2 waves of 64x64, two workgroups per CU.
 #include <cstdlib>
+#include <mutex>
 
 #include "xv_epilogue.h"
 
@@ -495,12 +496,16 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
     }
   }
   static int force = -1;        // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA weights, barrier per step; 0 = default
-  static bool attr_set = false;
+  static std::mutex init_mu;    // the attributes are per device; any thread may make the first launch on one
+  static bool attr_set[64] = {};
   static int diag = 0;              // XVEC_GEMM_DIAG: timing-only ablation switches of the LDS-DMA kernel (outputs invalid)
   const size_t smem128 = (size_t)4 * TILE_B;
   const size_t smemdma = (size_t)2 * DA_BYTES + 2 * DB_BYTES;
   const size_t smemw32 = (size_t)2 * DA_BYTES;      // two slabs; the 4 x 8 KB epilogue scratch overlays them
-  if (!attr_set) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> init_lock(init_mu);
+  if (!attr_set[dev & 63]) {
     const char* e = getenv("XVEC_GEMM_TILE");
     force = e ? atoi(e) : 0;
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel),
@@ -517,7 +522,7 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
     if (r != hipSuccess) return r;
     const char* e3 = getenv("XVEC_GEMM_DIAG");
     diag = e3 ? atoi(e3) : 0;
-    attr_set = true;
+    attr_set[dev & 63] = true;
   }
   const int w = a.K / a.cin > 0 && a.ldsbx == a.cin ? a.K / a.cin : 1;   // taps (dense: 1)
   const bool taps_ok = w <= 9 && (a.Kpad >> 5) % w == 0;   // slab halo: 128 + w - 1 <= DA_ROWS (136)

@@ -21,6 +21,8 @@
 //    exactly like the A tile and needs no bounds checks.
 //  * XCD-aware block order: consecutive ids on one XCD (id % 8) walk the N tiles of the same M
 //    tile, so the A panel is fetched once per XCD L2.
+#include <mutex>
+
 #include "xv_epilogue.h"
 
 namespace xv {
@@ -179,8 +181,12 @@ hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s) {
   const int nk_all = a.Kpad / BK;
   const int kper = (nk_all + ks - 1) / ks;
   const size_t smem = (size_t)4 * TILE_F * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::mutex init_mu;    // per-device attributes; any thread may make the first launch on a device
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> init_lock(init_mu);
+  if (!attr_set[dev & 63]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -190,7 +196,7 @@ hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<0>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set[dev & 63] = true;
   }
   GemmArgs b = a;
   b.ksplit = ks;
