@@ -246,3 +246,28 @@ def test_too_short_utterance_raises(stat_model):
     with pytest.raises(ValueError):
         tr.predict(np.zeros((14, 30), np.float32))
     tr.close()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_against_committed_oracle_embeddings(precision):
+    """The HIP path against vectors committed under tests/golden/ (generated by make_oracle_golden.py from the float64
+    oracle): a check that does not depend on running the oracle on this box."""
+    import importlib.util
+    import os
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_golden", os.path.join(golden, "make_oracle_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from tf_kaldi_speaker_amd import synth
+    with np.load(os.path.join(golden, "oracle_embeddings.npz"), allow_pickle=False) as z:
+        for name, (params, dim, wseed, fseed, frames) in mod.CASES.items():
+            if params.get("network_type") == "resnet_18":
+                weights = synth.synth_resnet_weights(params, seed=wseed)
+            else:
+                weights = synth.synth_weights(params, dim, seed=wseed)
+            feats = synth.synth_features(1, frames, dim, seed=fseed)[0]
+            tr, _ = _trainer(params, weights, dim, precision)
+            err = _rel(tr.predict(feats), z[name])
+            tr.close()
+            _note("committed_golden", precision, name, err)
+            assert err <= TOL, (name, err)

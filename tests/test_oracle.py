@@ -165,3 +165,17 @@ def test_predict_rank_handling_and_dim_truncation():
     np.testing.assert_allclose(e2, e3[1], rtol=1e-12)
     np.testing.assert_allclose(ref_numpy.predict(f[1][:, :7], w, p, 7), e2, rtol=1e-12)
     assert ref_numpy.predict(f[0], w, p, 7, node="tdnn3_relu").shape == (6, 32)
+
+
+def test_oracle_reproduces_its_committed_embeddings():
+    """Regression goldens of the oracle itself (tests/golden/make_oracle_golden.py): a change of ref_numpy or of the
+    synthetic generators shows up here.  Not a pin from the reference."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_oracle_golden", os.path.join(GOLD, "make_oracle_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with np.load(os.path.join(GOLD, "oracle_embeddings.npz"), allow_pickle=False) as z:
+        assert set(z.files) == set(mod.CASES)
+        for name in ("tdnn_stat", "tdnn_att"):          # the other two are checked on the GPU side (slower oracle)
+            got = mod.compute(name)
+            assert np.linalg.norm(got - z[name]) / np.linalg.norm(z[name]) < 1e-12, name
