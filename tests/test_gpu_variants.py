@@ -93,6 +93,47 @@ def test_alternative_gemm_kernels(tile, repo_root):
     assert worst <= TOL, (tile, worst)
 
 
+_TAIL_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+import torch
+from tf_kaldi_speaker_amd import synth
+from tf_kaldi_speaker_amd.params import Params
+from tf_kaldi_speaker_amd.trainer import Trainer
+params = dict(synth.TDNN_STAT_PARAMS)
+weights = synth.synth_weights(params, 30, seed=0)
+tr = Trainer(Params(**params), None, 30, single_cpu=True, device=0, precision=%(prec)r)
+tr.build("predict"); tr.load_weights(weights)
+B, T = 256, 300                                    # L3: 2336 tiles on 768 slots -> 32 tail tiles, L2: 64
+feats = torch.from_numpy(np.concatenate(synth.synth_features(B, T, 30, seed=5))).cuda()
+offs = np.arange(B + 1, dtype=np.int32) * T
+a = tr.predict_packed(feats, offs).cpu().numpy()
+b = tr.predict_packed(feats, offs).cpu().numpy()
+assert np.array_equal(a, b), "non-deterministic"
+np.save(%(out)r, a)
+"""
+
+
+def test_tail_ksplit_matches_plain_and_exact(tmp_path, repo_root):
+    """The K-split of the last, nearly empty round of tiles (gemm_bf16x3_tail_plan) against the same kernel without
+    it (XVEC_GEMM_TAIL=0) and against the exact fp32 path, at the BASELINE geometry where it is active."""
+    outs = {}
+    for tag, env_extra, prec in (("tail", {"XVEC_GEMM_TAIL": "1"}, "bf16x3"), ("plain", {"XVEC_GEMM_TAIL": "0"}, "bf16x3"),
+                                 ("exact", {}, "f32")):
+        out = str(tmp_path / (tag + ".npy"))
+        env = dict(os.environ, PYTHONPATH=repo_root + os.pathsep + os.environ.get("PYTHONPATH", ""), **env_extra)
+        r = subprocess.run([sys.executable, "-c", _TAIL_CHILD % {"root": repo_root, "prec": prec, "out": out}], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(out).astype(np.float64)
+
+    def rel(a, b):
+        return float(np.max(np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)))
+    assert rel(outs["tail"], outs["plain"]) <= 2e-6          # same products, different summation order in 96 tiles
+    assert not np.array_equal(outs["tail"], outs["plain"])   # ... so the path really was taken
+    assert rel(outs["tail"], outs["exact"]) <= TOL
+
+
 def test_vmcnt_retires_in_issue_order(tmp_path, repo_root):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
 // The activation fragment addresses use ONE swizzle and ONE row offset per lane ((32*mi + r) >> 1 == r >> 1 mod 8)
 // plus ds_read immediates, which frees the registers for the third weight buffer at 3 workgroups / CU.
 template <int NPS>
-__device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, int w, char* smem3) {
+__device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, int w, char* smem3, int cb_begin, int cb_end) {
   char* As = smem3;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -350,7 +350,7 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
   const int r32 = lane & 31, h = lane >> 5;
 
   const int ncb = (p.Kpad >> 5) / w;
-  const int nsteps = ncb * w;
+  const int nsteps = (cb_end - cb_begin) * w;      // channel blocks [cb_begin, cb_end): the whole K, or one K-split slice
   const int ngroups = (BM + w - 1 + 7) >> 3;
   const int lrow = lane >> 3, lpc = lane & 7;
   const int64_t a_row_bytes = (p.a_pitch ? p.a_pitch : p.ldsbx) * 4;
@@ -375,8 +375,8 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
   // (cb, j) of the current step, of the next one and of the one after
-  int cb = 0, j = 0, cb1 = 0, j1 = 1, cb2, j2;
-  if (j1 == w) { j1 = 0; cb1 = 1; }
+  int cb = cb_begin, j = 0, cb1 = cb_begin, j1 = 1, cb2, j2;
+  if (j1 == w) { j1 = 0; cb1 = cb_begin + 1; }
   cb2 = cb1; j2 = j1 + 1;
   if (j2 == w) { j2 = 0; cb2 = cb1 + 1; }
 
@@ -389,11 +389,13 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
   bf16x8 W0[4], W1[4], W2[4];            // [plane * 2 + ks]; W0: step 0, W1: step 1
   {
     const char* q1 = Wg + (int64_t)(1 < nsteps ? j1 * ncb + cb1 : 0) * 4096;
-    XV_GLD(W0[0], Wg, 0); XV_GLD(W0[1], Wg, 1024); XV_GLD(W0[2], Wg, 2048); XV_GLD(W0[3], Wg, 3072);
+    const char* q0 = Wg + (int64_t)cb_begin * 4096;               // step 0 = (cb_begin, tap 0)
+    XV_GLD(W0[0], q0, 0); XV_GLD(W0[1], q0, 1024); XV_GLD(W0[2], q0, 2048); XV_GLD(W0[3], q0, 3072);
     XV_GLD(W1[0], q1, 0); XV_GLD(W1[1], q1, 1024); XV_GLD(W1[2], q1, 2048); XV_GLD(W1[3], q1, 3072);
   }
-  for (int g = wave; g < ngroups; g += 4) dma_a(0, 0, g);
-  int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : 128;
+  // (a K-split slice starts at block cb_begin of the row; slices exist in the 1-D form only)
+  for (int g = wave; g < ngroups; g += 4) dma_a((int64_t)cb_begin * 128, cb_begin & 1, g);
+  int64_t koff_next = (kbt == 1 && p.a_pitch) ? tap_bytes : (int64_t)(cb_begin + 1) * 128;
   int blk_next = (kbt == 1 && p.a_pitch) ? 0 : 1;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -419,7 +421,7 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
     read_frag(0);
     read_frag(1);
     {
-      const int64_t ksrc = cb + 1 < ncb ? koff_next : 0;
+      const int64_t ksrc = cb + 1 < cb_end ? koff_next : 0;
 #pragma unroll
       for (int i = 0; i < NPS; ++i) dma_a(ksrc, (cb + 1) & 1, min((j * NPS + i) * 4 + wave, ngroups - 1));
     }
@@ -471,7 +473,62 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_kernel(GemmArgs p, i
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   const int tile = xcd_remap(blockIdx.x, nMt * nNt);
   const int mt = tile / nNt, nt = tile - mt * nNt;
-  w14p2_tile<NPS>(p, mt * BM, nt * BN, w, smem3);
+  w14p2_tile<NPS>(p, mt * BM, nt * BN, w, smem3, 0, (p.Kpad >> 5) / w);
+}
+
+// K-split form for the M tiles of the last, nearly empty round (gemm_bf16x3_tail_plan): workgroup = (tile, slice);
+// slice s accumulates channel blocks [s * ncb / S, (s + 1) * ncb / S) and stores its RAW accumulators to
+// partial[s][row - mt0 * 128][Npad]; bf16x3_tail_reduce_kernel adds the slices in order and runs the epilogue.
+template <int NPS>
+__global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_tail_kernel(GemmArgs p, int mt0, int nNt, int w, int S) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  const int split = blockIdx.x % S, tile = blockIdx.x / S;
+  const int mt = mt0 + tile / nNt, nt = tile % nNt;
+  const int ncb = (p.Kpad >> 5) / w, per = ncb / S;
+  GemmArgs q = p;
+  q.raw = 1;
+  q.act = ACT_NONE;                      // raw partial sums: no scale / shift / activation before the reduce
+  q.alpha = nullptr;
+  q.Y = p.partial + ((int64_t)split * p.tail_mt - mt0) * (int64_t)BM * p.Npad;   // row m of the tile -> slice row m - mt0*128
+  q.ldy = p.Npad;
+  q.N = p.Npad;
+  q.M = (mt0 + p.tail_mt) * BM;          // every row of the tail tiles is stored (rows >= M are never read back)
+  q.Ysb = nullptr;
+  q.rowmap = nullptr;
+  q.R = nullptr;
+  q.pool_part = nullptr;
+  w14p2_tile<NPS>(q, mt * BM, nt * BN, w, smem3, split * per, (split + 1) * per);
+}
+
+// one thread per (tail row, 4 channels): ordered sum of the K slices, then the usual epilogue (BN scale/shift,
+// activation, rowmap compaction, fp32 and/or split-blocked store).  Padding channels (n >= N) are written as zeros.
+__global__ void bf16x3_tail_reduce_kernel(GemmArgs p, int mt0, int S) {
+  const int quads = p.Npad >> 2;
+  const int64_t rows = (int64_t)p.tail_mt * BM;
+  const int64_t total = rows * quads;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / quads;
+    const int n = (int)(i - r * quads) * 4;
+    const int64_t m = (int64_t)mt0 * BM + r;
+    if (m >= p.M) continue;
+    const int orow = p.rowmap ? p.rowmap[m] : (int)m;
+    if (orow < 0) continue;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(p.partial + ((int64_t)s * rows + r) * p.Npad + n);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n + e < p.N) v[e] = apply_act(fmaf(acc[e], p.scale[n + e], p.shift[n + e]), p.act, p.alpha ? p.alpha[n + e] : 0.f);
+    if (p.Y && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;     // N % 4 == 0 (wide epilogue)
+    if (p.Ysb && n < p.ldsb) {
+      uint32_t h01, l01, h23, l23;
+      split2(v[0], v[1], h01, l01);
+      split2(v[2], v[3], h23, l23);
+      char* blk = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128 + (n & 31) * 2;
+      *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
+      *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
+    }
+  }
 }
 
 #undef XV_GLD
@@ -482,6 +539,26 @@ long long* g_trace = nullptr;      // debug trace buffer (device), kTraceWgs wor
 int g_trace_wgs = 0;
 constexpr int kTraceWgs = 16384;
 }  // namespace
+
+int64_t gemm_bf16x3_tail_plan(int M, int Kpad, int Npad, int w, int* tail_mt, int* splits) {
+  *tail_mt = 0;
+  *splits = 1;
+  static int enabled = -1;               // XVEC_GEMM_TAIL=0 switches the tail handling off (A/B)
+  if (enabled < 0) { const char* e = getenv("XVEC_GEMM_TAIL"); enabled = e ? atoi(e) : 1; }
+  if (!enabled || w < 1 || w > 9 || (Kpad >> 5) % w != 0) return 0;
+  const int slots = 256 * 3;             // CUs x resident workgroups of the default kernel
+  const int nMt = (M + BM - 1) / BM, nNt = Npad / BN, tiles = nMt * nNt, ncb = (Kpad >> 5) / w;
+  const int r = tiles % slots;
+  if (tiles <= slots || r == 0 || r > slots / 4) return 0;        // only a nearly empty last round is worth splitting
+  const int mt = (r + nNt - 1) / nNt;
+  int S = 0;
+  for (int c = 8; c >= 2; c >>= 1)
+    if (ncb % c == 0 && ncb / c >= 2 && mt * nNt * c <= 256) { S = c; break; }   // about one slice workgroup per CU
+  if (S == 0) return 0;
+  *tail_mt = mt;
+  *splits = S;
+  return (int64_t)S * mt * BM * Npad * (int64_t)sizeof(float);
+}
 
 hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
   if (a_in.M <= 0) return hipSuccess;
@@ -520,6 +597,12 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
     if (r != hipSuccess) return r;
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+    if (r != hipSuccess) return r;
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+    if (r != hipSuccess) return r;
     const char* e3 = getenv("XVEC_GEMM_DIAG");
     diag = e3 ? atoi(e3) : 0;
     attr_set[dev & 63] = true;
@@ -528,10 +611,23 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
   const bool taps_ok = w <= 9 && (a.Kpad >> 5) % w == 0;   // slab halo: 128 + w - 1 <= DA_ROWS (136)
   if (force != 1 && force != 128 && taps_ok) {   // default: 1 x 4 waves, weights in registers two steps ahead
     const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
-    const dim3 grid(nMt * nNt), block(256);
+    // tail handling decided at plan time (the plan owns the partial workspace): the last tail_mt M tiles go K-split
+    const bool tail = a.tail_mt > 0 && a.ksplit > 1 && a.partial && !a.a_pitch && !a.pool_part && !a.R && !a.raw &&
+                      a.tail_mt < nMt && (a.N & 3) == 0;
+    const int nMain = tail ? nMt - a.tail_mt : nMt;
+    const dim3 grid(nMain * nNt), block(256);
     if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
-    if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1>), grid, block, smemw32, s, a, nMt, nNt, w);
-    else        hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4>), grid, block, smemw32, s, a, nMt, nNt, w);
+    if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1>), grid, block, smemw32, s, a, nMain, nNt, w);
+    else        hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4>), grid, block, smemw32, s, a, nMain, nNt, w);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !tail) return e;
+    const dim3 tgrid(a.tail_mt * nNt * a.ksplit);
+    if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<1>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
+    else        hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<4>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int64_t total = (int64_t)a.tail_mt * BM * (a.Npad >> 2);
+    hipLaunchKernelGGL(bf16x3_tail_reduce_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, s, a, nMain, a.ksplit);
     return hipGetLastError();
   }
   if (force != 128 && taps_ok) {

@@ -47,7 +47,9 @@ struct GemmArgs {
   // sums the slices in order (deterministic) and applies the epilogue.
   int ksplit;             // 0/1 = off
   int raw;                // epilogue: store acc unchanged (scale 1, shift 0, no activation)
-  float* partial;         // [ksplit][M][Npad] fp32 workspace
+  float* partial;         // [ksplit][M][Npad] fp32 workspace (bf16x3 tail form: [ksplit][tail_mt * 128][Npad])
+  int tail_mt = 0;        // bf16x3 kernel: the last `tail_mt` M tiles are computed K-split in `ksplit` slices (see
+                          // gemm_bf16x3_tail_plan) and finished by a reduce kernel
   // fused statistics pooling (dense layer feeding statistics_pooling, model/pooling.py:27-52):
   // instead of storing the activations, every 64-row wave tile writes, per channel and per
   // utterance segment inside the tile, sum(x) and sum((x - segment mean)^2) to
@@ -77,6 +79,11 @@ hipError_t launch_gemm_f32(const GemmArgs& a, bool aligned, hipStream_t s);
 // number of K slices launch_gemm_f32 will use for this shape (1 = no split); the caller provides
 // `partial` of ksplit * M * Npad floats when > 1.
 int gemm_f32_ksplit(int M, int Kpad, int Npad);
+
+// Tail balancing of the bf16x3 kernel (1-D layers): when the last round of 128x128 tiles over the chip's 768
+// workgroup slots would be nearly empty, its M tiles are split along K into `*splits` slices each (deterministic:
+// raw partials + an ordered reduce).  Returns the partial workspace in bytes (0 = no tail handling).
+int64_t gemm_bf16x3_tail_plan(int M, int Kpad, int Npad, int w, int* tail_mt, int* splits);
 
 // fp32 frames -> split-blocked im2col rows for a small-cin first layer:
 //   out row m, k < w*cin: x[(m + k / cin) * ldx + k % cin]; zero padded to ldsb columns.

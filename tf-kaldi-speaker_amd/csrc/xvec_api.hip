@@ -167,7 +167,8 @@ struct PlanStep {
   int M = 0;                    // GEMM rows to compute
   int rowmap = -1;              // index into plan rowmaps (conv layers)
   int64_t scratch_off = -1;     // per-step scratch (im2col rows / split-K partials), released after the step
-  int ksplit = 1;               // split-K slices of a small-M fp32 GEMM
+  int ksplit = 1;               // split-K slices of a small-M fp32 GEMM, or of the tail M tiles of a bf16x3 GEMM
+  int tail_mt = 0;              // bf16x3: M tiles computed K-split (gemm_bf16x3_tail_plan)
   bool fuse_pool = false;       // GEMM: emit pooling partials instead of activations; STAT_POOL: finalize only
   bool unpad_to_out = false;    // grid-valued target node: GEMM writes the padded grid, then it is unpadded into `out`
   int64_t flops = 0, bytes = 0;
@@ -889,6 +890,8 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       } else if (!L.use_split && op.out != fused_value) {
         st.ksplit = gemm_f32_ksplit(st.M, L.Kpad, L.Npad);
         if (st.ksplit > 1) scratch = (int64_t)st.ksplit * st.M * L.Npad * 4;
+      } else if (L.use_split && L.mode == 0 && op.out != fused_value && op.in1 <= 0) {
+        scratch = gemm_bf16x3_tail_plan(st.M, L.Kpad, L.Npad, L.w, &st.tail_mt, &st.ksplit);
       }
       if (scratch > 0) {
         step_scratch = align_up(scratch, kAlign);
@@ -1170,6 +1173,11 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           a.Xsb = ws + st.in0_sb_off;
           a.ldsbx = L.mode == 0 ? sb_ld(L.cin) : 0;
           a.Wsb = L.wsb.p; a.Wfr = L.wfr.p;
+          if (st.tail_mt > 0 && st.scratch_off >= 0) {
+            a.tail_mt = st.tail_mt;
+            a.ksplit = st.ksplit;
+            a.partial = reinterpret_cast<float*>(ws + st.scratch_off);
+          }
           XV_HIP(h, launch_gemm_bf16x3(a, s));
           if (st.unpad_to_out)
             XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.cols,
