@@ -21,6 +21,7 @@ python profiles/summarize_trace.py $(find $out/trace -name "*kernel_trace.csv" |
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 for c in sq fetch write; do python profiles/summarize_pmc.py $(find $out/pmc_$c -name "*counter_collection.csv" | head -1) > $out/pmc_${c}_summary.txt 2>&1; done
 rocm-smi --showproductname > $out/device.txt 2>&1
+python profiles/make_traffic.py $out >> $out/progress.txt 2>&1
 rm -rf $out/trace $out/pmc_sq $out/pmc_fetch $out/pmc_write
 step done
 cat $out/progress.txt; head -c 600 $out/bench_bf16x3.json
