@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs p, int nMt
 }
 
 // ------------------------------------------------------------------------------------------
-// 128x128 LDS-DMA kernel (the default): same 2x2 waves of 64x64, two workgroups per CU, but
+// 128x128 LDS-DMA kernel (the round's first default, now the A/B baseline XVEC_GEMM_TILE=1): same 2x2 waves of
+// 64x64, two workgroups per CU, but
 //  * operands go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write: the
 //    register-staged kernel above spends ~55% of the LDS port on ds_write_b128 at full MFMA rate);
 //  * LDS rows are unpadded 128-byte blocks (the DMA writes 64 lanes x 16 B linearly), made
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs p, int nMt
 // (whose vmcnt(0) retires the DMA issued ~800 cycles earlier).
 namespace {
 constexpr int DROW = 128;                          // unpadded LDS row
-constexpr int DA_ROWS = 136;                       // 128 + (w-1 <= 7) halo rows, multiple of 8
+constexpr int DA_ROWS = 136;                       // 128 + (w-1 <= 8) halo rows, multiple of 8
 constexpr int DA_BYTES = DA_ROWS * DROW;
 constexpr int DB_BYTES = BN * DROW;
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -333,12 +334,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
 #define XV_WAIT2(N, ra, rb) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra), "+v"(rb) : "n"(N))
 
 //  * the weight fragments are prefetched TWO steps ahead (three register buffers of 4 fragments).
-// With one step of lead a workgroup alone on a CU is bound by the load->use latency (~0.9 us per step against
+//    With one step of lead a workgroup alone on a CU is bound by the load->use latency (~0.9 us per step against
 // 0.4 us of MFMA work), so only three resident workgroups together cover the matrix pipe and every prologue,
 // epilogue and the tail of the launch leave it under-fed; with two steps of lead two workgroups suffice.
 //   VMEM order per step:  D x NPS (top) , a0 (group 0) a1 (group 2) a2 (group 4) a3 (group 6)   [for step s+2]
 //   step s+2: before group 0 wait vmcnt(7+2*NPS) [a0,a1 of s] ; before group 4 vmcnt(7+2*NPS) [a2,a3 of s] ;
 //   slab switch vmcnt(4).
+//  * K-split slices: the tile function takes the channel-block range [cb_begin, cb_end) so that the tail form
+//    (gemm_bf16x3_tail_plan) can run one slice of K per workgroup.
 // The activation fragment addresses use ONE swizzle and ONE row offset per lane ((32*mi + r) >> 1 == r >> 1 mod 8)
 // plus ds_read immediates, which frees the registers for the third weight buffer at 3 workgroups / CU.
 template <int NPS>
