@@ -182,6 +182,20 @@ int xv_frontend_cmn_select(int device, const float* feats_dev, int ld, int dim, 
                            int batch, const int32_t* src_rows_dev, int64_t out_rows, int cmn_window, int center,
                            int min_window, double* scratch_dev, float* out_dev, void* stream);
 
+/* ---- post-step on the GPU (csrc/post.hip): what the reference runs as Kaldi binaries behind extract.py
+ * (egs/voxceleb/v1/nnet/run_extract_embeddings.sh:80-103).
+ * xv_length_normalize = `ivector-normalize-length [--scaleup=false]` (:86,88,101): out[r] = x[r] / ratio,
+ *   ratio = ||x[r]||_2 (scaleup 0) or ||x[r]||_2 / sqrt(dim) (scaleup 1); a zero vector is copied unchanged.
+ * xv_speaker_mean = `ivector-mean ark:spk2utt` (:87,92): speaker s owns utt_index[spk_offsets[s] .. spk_offsets[s+1])
+ *   (row numbers of x, spk2utt order, utterances without a vector already removed by the host); out[s] = their
+ *   float32 sum in that order times float(1 / count); a speaker without utterances gets zeros (the host drops it).
+ * x_dev [rows, ldx], out_dev [rows | num_speakers, ldo] device float32; in-place (out_dev == x_dev) is allowed for
+ * xv_length_normalize. */
+int xv_length_normalize(int device, const float* x_dev, int64_t ldx, int64_t rows, int dim, int scaleup, float* out_dev,
+                        int64_t ldo, void* stream);
+int xv_speaker_mean(int device, const float* x_dev, int64_t ldx, int dim, const int32_t* spk_offsets_dev,
+                    const int32_t* utt_index_dev, int64_t num_speakers, float* out_dev, int64_t ldo, void* stream);
+
 /* ---- host-side ark I/O (csrc/ark_io.cpp; no HIP calls, usable without a GPU) ---------------------
  * Batch counterpart of dataset/kaldi_io.py read_mat_ark (:974-994, records per _read_mat_binary
  * :1014-1031 / _read_compressed_mat :1071-1115) and write_vec_flt (:915-946): the extraction driver
@@ -190,6 +204,17 @@ typedef struct xv_ark_reader xv_ark_reader;
 /* Open a binary matrix ark by path, or wrap an already open descriptor (path == NULL; e.g. the read
  * end of a `cmd |` rspecifier pipe).  The descriptor is closed by xv_ark_close only when opened here. */
 int xv_ark_open(const char* path, int fd, xv_ark_reader** out);
+/* Open a Kaldi script file (`key rxfilename` lines, rxfilename = `file` or `file:offset`; what
+ * dataset/kaldi_io.py read_mat_scp :953-972 walks one record per call, and what `scp:${sdata}/feats.scp` means
+ * to the Kaldi binaries of run_extract_embeddings.sh:47).  Records are reached by seeking; consecutive
+ * entries of one ark are read through one descriptor.  XV_ERR_UNSUPPORTED for ranges / pipes in the table.
+ * xv_ark_next_batch then delivers the table's records in table order.  Float-vector records ('FV ', 'DV ';
+ * e.g. vad.scp) are delivered as [dim, 1] matrices by both readers. */
+int xv_ark_open_scp(const char* scp_path, xv_ark_reader** out);
+int64_t xv_ark_scp_count(const xv_ark_reader* r);
+/* rows / cols of every record of the table (headers only: one seek + one short read per record; the
+ * utterance lengths the sharder needs, utils/split_data.sh's role in run_extract_embeddings.sh:43).  Rewinds. */
+int xv_ark_scp_shapes(xv_ark_reader* r, int32_t* rows, int32_t* cols, int64_t capacity);
 /* Read consecutive utterances ('FM ', 'DM ', 'CM ' records) until `max_frames` frames or `max_utts`
  * utterances are collected or the next one does not fit.  Utterances with fewer than `min_frames` rows
  * are dropped and counted (extract.py:65-67).  dst: float32 [frames, dim] row-major, utterance i =
@@ -198,6 +223,9 @@ int xv_ark_open(const char* path, int fd, xv_ark_reader** out);
 int xv_ark_next_batch(xv_ark_reader* r, int64_t max_frames, int max_utts, int min_frames, float* dst,
                       int64_t dst_capacity, int32_t* offsets, char* keys, int64_t keys_capacity, int* n_utts,
                       int* dim);
+/* Shape of the record whose header has been parsed but not delivered (after xv_ark_next_batch failed with
+ * "a single utterance does not fit ..."): lets the caller retry with a larger buffer.  XV_ERR_STATE if none. */
+int xv_ark_pending_shape(const xv_ark_reader* r, int32_t* rows, int32_t* cols);
 int64_t xv_ark_skipped(const xv_ark_reader* r);
 const char* xv_ark_error(const xv_ark_reader* r);
 void xv_ark_close(xv_ark_reader* r);

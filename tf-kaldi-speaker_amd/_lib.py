@@ -24,8 +24,8 @@ XV_ACT_RELU, XV_ACT_LRELU, XV_ACT_PRELU = 0, 1, 2
 EXPORTS = ["xv_version", "xv_create", "xv_set_tensor", "xv_finalize", "xv_node_id", "xv_node_context",
            "xv_plan_create", "xv_plan_query", "xv_plan_destroy", "xv_forward", "xv_profile_begin", "xv_profile_end",
            "xv_destroy", "xv_last_error",
-           "xv_frontend_cmn_select",
-           "xv_ark_open", "xv_ark_next_batch", "xv_ark_skipped", "xv_ark_error", "xv_ark_close", "xv_ark_format_vectors"]
+           "xv_frontend_cmn_select", "xv_length_normalize", "xv_speaker_mean",
+           "xv_ark_open", "xv_ark_open_scp", "xv_ark_scp_count", "xv_ark_scp_shapes", "xv_ark_next_batch", "xv_ark_pending_shape", "xv_ark_skipped", "xv_ark_error", "xv_ark_close", "xv_ark_format_vectors"]
 
 
 class ModelDesc(C.Structure):
@@ -96,8 +96,15 @@ def load():
     lib.xv_destroy.argtypes = [vp]
     lib.xv_destroy.restype = None
     lib.xv_frontend_cmn_select.argtypes = [i32, vp, i32, i32, vp, i32, vp, i64, i32, i32, i32, vp, vp, vp]
+    lib.xv_length_normalize.argtypes = [i32, vp, i64, i64, i32, i32, vp, i64, vp]
+    lib.xv_speaker_mean.argtypes = [i32, vp, i64, i32, vp, vp, i64, vp, i64, vp]
     lib.xv_ark_open.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    lib.xv_ark_open_scp.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.xv_ark_scp_count.argtypes = [vp]
+    lib.xv_ark_scp_count.restype = i64
+    lib.xv_ark_scp_shapes.argtypes = [vp, vp, vp, i64]
     lib.xv_ark_next_batch.argtypes = [vp, i64, i32, i32, vp, i64, vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
+    lib.xv_ark_pending_shape.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.xv_ark_skipped.argtypes = [vp]
     lib.xv_ark_skipped.restype = i64
     lib.xv_ark_error.argtypes = [vp]
@@ -108,7 +115,7 @@ def load():
     lib.xv_ark_format_vectors.restype = i64
     for n in EXPORTS:
         if n not in ("xv_version", "xv_last_error", "xv_plan_destroy", "xv_destroy", "xv_ark_skipped", "xv_ark_error",
-                     "xv_ark_close", "xv_ark_format_vectors"):
+                     "xv_ark_close", "xv_ark_format_vectors", "xv_ark_scp_count"):
             getattr(lib, n).restype = i32
     _lib = lib
     return lib

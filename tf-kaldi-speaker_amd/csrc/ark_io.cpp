@@ -12,6 +12,8 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -34,6 +36,14 @@ struct xv_ark_reader {
   int32_t pending_rows = 0, pending_cols = 0;
   float pending_min = 0.f, pending_range = 0.f;
   int64_t skipped_short = 0;
+  int64_t file_pos = 0;             // file offset of buf[end] (bytes consumed from fd so far)
+  // scp mode (xv_ark_open_scp): the table of `key rxfile` lines; records are reached by seeking
+  struct ScpEntry { std::string key; int path; int64_t offset; };
+  bool scp = false;
+  std::vector<ScpEntry> entries;
+  std::vector<std::string> paths;
+  size_t next_entry = 0;
+  int cur_path = -1;
 };
 
 namespace {
@@ -59,6 +69,7 @@ bool fill(xv_ark_reader* r, size_t n) {
     }
     if (got == 0) { r->eof = true; break; }
     r->end += (size_t)got;
+    r->file_pos += got;
   }
   return r->end - r->pos >= n;
 }
@@ -68,7 +79,52 @@ int fail(xv_ark_reader* r, const char* msg) {
   return XV_ERR_INVALID;
 }
 
-// next record header -> pending_*; returns 1 = header parsed, 0 = clean end of stream, <0 error
+// record header after the key ("\0B" + type + dimensions) -> pending_*; 1 = parsed, <0 error.
+// Float vectors ('FV ' / 'DV ', e.g. per-frame VAD decisions) are delivered as [dim, 1] matrices.
+int parse_matrix_header(xv_ark_reader* r, std::string& key) {
+  if (!fill(r, 5)) return fail(r, "unexpected end of stream after the key");
+  const unsigned char* p = r->buf.data() + r->pos;
+  if (p[0] != 0 || p[1] != 'B') return fail(r, "text-mode or unknown record (expected \\\\0B)");
+  int kind = 0;
+  bool vec = false;
+  if (!memcmp(p + 2, "FM ", 3)) kind = 1;
+  else if (!memcmp(p + 2, "DM ", 3)) kind = 2;
+  else if (!memcmp(p + 2, "CM ", 3)) kind = 3;
+  else if (!memcmp(p + 2, "FV ", 3)) { kind = 1; vec = true; }
+  else if (!memcmp(p + 2, "DV ", 3)) { kind = 2; vec = true; }
+  else return fail(r, "unknown matrix header (FM / DM / CM / FV / DV are supported)");
+  r->pos += 5;
+  if (kind == 3) {
+    if (!fill(r, 16)) return fail(r, "truncated compressed-matrix header");
+    const unsigned char* q = r->buf.data() + r->pos;
+    memcpy(&r->pending_min, q, 4);
+    memcpy(&r->pending_range, q + 4, 4);
+    memcpy(&r->pending_rows, q + 8, 4);
+    memcpy(&r->pending_cols, q + 12, 4);
+    r->pos += 16;
+  } else if (vec) {
+    if (!fill(r, 5)) return fail(r, "truncated vector header");
+    const unsigned char* q = r->buf.data() + r->pos;
+    if (q[0] != 4) return fail(r, "vector header: int-size marker missing");
+    memcpy(&r->pending_rows, q + 1, 4);
+    r->pending_cols = 1;
+    r->pos += 5;
+  } else {
+    if (!fill(r, 10)) return fail(r, "truncated matrix header");
+    const unsigned char* q = r->buf.data() + r->pos;
+    if (q[0] != 4 || q[5] != 4) return fail(r, "matrix header: int-size markers missing");
+    memcpy(&r->pending_rows, q + 1, 4);
+    memcpy(&r->pending_cols, q + 6, 4);
+    r->pos += 10;
+  }
+  if (r->pending_rows < 0 || r->pending_cols < 0) return fail(r, "negative matrix dimension");
+  r->pending_key.swap(key);
+  r->pending_kind = kind;
+  r->have_pending = true;
+  return 1;
+}
+
+// next record header of a sequential ark -> pending_*; returns 1 = header parsed, 0 = clean end of stream, <0 error
 int parse_header(xv_ark_reader* r) {
   // key: bytes up to the first space
   std::string key;
@@ -98,36 +154,43 @@ int parse_header(xv_ark_reader* r) {
   while (a < key.size() && (key[a] == '\n' || key[a] == '\r' || key[a] == '\t')) ++a;
   key.erase(0, a);
   if (key.empty()) return fail(r, "empty key");
-  if (!fill(r, 5)) return fail(r, "unexpected end of stream after the key");
-  const unsigned char* p = r->buf.data() + r->pos;
-  if (p[0] != 0 || p[1] != 'B') return fail(r, "text-mode or unknown record (expected \\\\0B)");
-  int kind = 0;
-  if (!memcmp(p + 2, "FM ", 3)) kind = 1;
-  else if (!memcmp(p + 2, "DM ", 3)) kind = 2;
-  else if (!memcmp(p + 2, "CM ", 3)) kind = 3;
-  else return fail(r, "unknown matrix header (FM / DM / CM are supported)");
-  r->pos += 5;
-  if (kind == 3) {
-    if (!fill(r, 16)) return fail(r, "truncated compressed-matrix header");
-    const unsigned char* q = r->buf.data() + r->pos;
-    memcpy(&r->pending_min, q, 4);
-    memcpy(&r->pending_range, q + 4, 4);
-    memcpy(&r->pending_rows, q + 8, 4);
-    memcpy(&r->pending_cols, q + 12, 4);
-    r->pos += 16;
-  } else {
-    if (!fill(r, 10)) return fail(r, "truncated matrix header");
-    const unsigned char* q = r->buf.data() + r->pos;
-    if (q[0] != 4 || q[5] != 4) return fail(r, "matrix header: int-size markers missing");
-    memcpy(&r->pending_rows, q + 1, 4);
-    memcpy(&r->pending_cols, q + 6, 4);
-    r->pos += 10;
+  return parse_matrix_header(r, key);
+}
+
+// scp mode: position the descriptor at `offset` of the current file; bytes already in the read-ahead window are kept
+int seek_to(xv_ark_reader* r, int64_t offset) {
+  const int64_t cur = r->file_pos - (int64_t)(r->end - r->pos);
+  if (offset >= cur && offset <= r->file_pos) {
+    r->pos += (size_t)(offset - cur);
+    return XV_OK;
   }
-  if (r->pending_rows < 0 || r->pending_cols < 0) return fail(r, "negative matrix dimension");
-  r->pending_key.swap(key);
-  r->pending_kind = kind;
-  r->have_pending = true;
-  return 1;
+  if (lseek(r->fd, (off_t)offset, SEEK_SET) < 0) return fail(r, "lseek failed (scp entries need a seekable file)");
+  r->pos = r->end = 0;
+  r->file_pos = offset;
+  r->eof = false;
+  return XV_OK;
+}
+
+// scp mode: header of the next table entry -> pending_*; 1 = parsed, 0 = end of table, <0 error
+int parse_scp_entry(xv_ark_reader* r) {
+  if (r->next_entry >= r->entries.size()) return 0;
+  const xv_ark_reader::ScpEntry& e = r->entries[r->next_entry++];
+  if (e.path != r->cur_path) {
+    if (r->fd >= 0) close(r->fd);
+    r->fd = open(r->paths[e.path].c_str(), O_RDONLY);
+    if (r->fd < 0) {
+      r->err = "cannot open " + r->paths[e.path] + ": " + strerror(errno);
+      return XV_ERR_INVALID;
+    }
+    r->cur_path = e.path;
+    r->pos = r->end = 0;
+    r->file_pos = 0;
+    r->eof = false;
+  }
+  const int rc = seek_to(r, e.offset);
+  if (rc < 0) return rc;
+  std::string key = e.key;
+  return parse_matrix_header(r, key);
 }
 
 // payload of the pending record -> dst (float32 row-major) or skipped when dst == nullptr
@@ -154,6 +217,7 @@ int read_payload(xv_ark_reader* r, float* dst) {
         if (got == 0) { r->eof = true; return fail(r, "truncated matrix payload"); }
         out += got;
         need -= (size_t)got;
+        r->file_pos += got;
       }
       return XV_OK;
     }
@@ -226,6 +290,74 @@ int xv_ark_open(const char* path, int fd, xv_ark_reader** out) {
   return XV_OK;
 }
 
+int xv_ark_open_scp(const char* scp_path, xv_ark_reader** out) {
+  if (!out || !scp_path) return XV_ERR_INVALID;
+  *out = nullptr;
+  FILE* f = fopen(scp_path, "r");
+  if (!f) return XV_ERR_INVALID;
+  xv_ark_reader* r = new (std::nothrow) xv_ark_reader();
+  if (!r) { fclose(f); return XV_ERR_HIP; }
+  r->scp = true;
+  r->own_fd = true;
+  r->buf.resize(kChunk);
+  char* line = nullptr;
+  size_t cap = 0;
+  ssize_t len;
+  bool bad = false;
+  while ((len = getline(&line, &cap, f)) >= 0) {
+    while (len > 0 && (line[len - 1] == '\n' || line[len - 1] == '\r' || line[len - 1] == ' ' || line[len - 1] == '\t')) line[--len] = 0;
+    char* p = line;
+    while (*p == ' ' || *p == '\t') ++p;
+    if (!*p) continue;
+    char* sp = p;
+    while (*sp && *sp != ' ' && *sp != '\t') ++sp;
+    if (!*sp) { bad = true; break; }                       // a key without an rxfilename
+    std::string key(p, sp - p);
+    while (*sp == ' ' || *sp == '\t') ++sp;
+    std::string rx(sp);
+    if (rx.empty() || rx.back() == ']' || rx.back() == '|') { bad = true; break; }   // ranges / pipes: not handled natively
+    int64_t offset = 0;
+    const size_t colon = rx.rfind(':');
+    if (colon != std::string::npos && colon + 1 < rx.size() &&
+        rx.find_first_not_of("0123456789", colon + 1) == std::string::npos) {
+      offset = strtoll(rx.c_str() + colon + 1, nullptr, 10);
+      rx.erase(colon);
+    }
+    int pi = -1;
+    if (!r->paths.empty() && r->paths.back() == rx) pi = (int)r->paths.size() - 1;     // consecutive entries share arks
+    if (pi < 0)
+      for (size_t i = 0; i < r->paths.size(); ++i) if (r->paths[i] == rx) { pi = (int)i; break; }
+    if (pi < 0) { r->paths.push_back(rx); pi = (int)r->paths.size() - 1; }
+    r->entries.push_back({std::move(key), pi, offset});
+  }
+  free(line);
+  fclose(f);
+  if (bad) { delete r; return XV_ERR_UNSUPPORTED; }
+  *out = r;
+  return XV_OK;
+}
+
+int64_t xv_ark_scp_count(const xv_ark_reader* r) { return (r && r->scp) ? (int64_t)r->entries.size() : XV_ERR_INVALID; }
+
+int xv_ark_scp_shapes(xv_ark_reader* r, int32_t* rows, int32_t* cols, int64_t capacity) {
+  if (!r || !r->scp || !rows || !cols || capacity < (int64_t)r->entries.size()) return XV_ERR_INVALID;
+  r->err.clear();
+  r->next_entry = 0;
+  r->have_pending = false;
+  int rc = XV_OK;
+  for (size_t i = 0; i < r->entries.size(); ++i) {
+    rc = parse_scp_entry(r);
+    if (rc <= 0) { rc = rc == 0 ? XV_ERR_INVALID : rc; break; }
+    rows[i] = r->pending_rows;
+    cols[i] = r->pending_cols;
+    r->have_pending = false;
+    rc = XV_OK;
+  }
+  r->next_entry = 0;                     // rewind: the table can be read after it has been measured
+  r->have_pending = false;
+  return rc;
+}
+
 int xv_ark_next_batch(xv_ark_reader* r, int64_t max_frames, int max_utts, int min_frames, float* dst,
                       int64_t dst_capacity, int32_t* offsets, char* keys, int64_t keys_capacity, int* n_utts,
                       int* dim) {
@@ -236,7 +368,7 @@ int xv_ark_next_batch(xv_ark_reader* r, int64_t max_frames, int max_utts, int mi
   offsets[0] = 0;
   while (n < max_utts && frames < max_frames) {
     if (!r->have_pending) {
-      const int rc = parse_header(r);
+      const int rc = r->scp ? parse_scp_entry(r) : parse_header(r);
       if (rc < 0) return rc;
       if (rc == 0) break;
     }
@@ -268,6 +400,13 @@ int xv_ark_next_batch(xv_ark_reader* r, int64_t max_frames, int max_utts, int mi
   *n_utts = n;
   *dim = d < 0 ? 0 : d;
   return n;
+}
+
+int xv_ark_pending_shape(const xv_ark_reader* r, int32_t* rows, int32_t* cols) {
+  if (!r || !rows || !cols || !r->have_pending) return XV_ERR_STATE;
+  *rows = r->pending_rows;
+  *cols = r->pending_cols;
+  return XV_OK;
 }
 
 int64_t xv_ark_skipped(const xv_ark_reader* r) { return r ? r->skipped_short : 0; }

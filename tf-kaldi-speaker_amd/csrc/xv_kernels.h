@@ -134,6 +134,12 @@ hipError_t launch_cmn_select(const float* x, int64_t ld, int dim, const int32_t*
                              const int32_t* src, int64_t out_rows, int window, int center, int min_window, float* out,
                              hipStream_t s);
 
+// post-step (csrc/post.hip): ivector-normalize-length / ivector-mean of run_extract_embeddings.sh:80-103
+hipError_t launch_length_norm(const float* x, int64_t ldx, int64_t rows, int dim, int scaleup, float* y, int64_t ldy,
+                              hipStream_t s);
+hipError_t launch_speaker_mean(const float* x, int64_t ldx, int dim, const int32_t* spk_off, const int32_t* utt,
+                               int64_t num_spk, float* out, int64_t ldo, hipStream_t s);
+
 // attention scores (model/pooling.py:189-194): score[r, h] = scale * sum_d key[r, h*dk_h + d] * q[h, d]
 // (split_key) or sum_d key[r, d] * q[h, d] (no split; dk_h == dk).
 hipError_t launch_att_scores(const float* key, int64_t ldk, int64_t rows, const float* query, int H,

@@ -1325,6 +1325,29 @@ int xv_frontend_cmn_select(int device, const float* feats_dev, int ld, int dim, 
   return XV_OK;
 }
 
+int xv_length_normalize(int device, const float* x_dev, int64_t ldx, int64_t rows, int dim, int scaleup, float* out_dev,
+                        int64_t ldo, void* stream) {
+  if (!x_dev || !out_dev) return fail(nullptr, XV_ERR_INVALID, "xv_length_normalize: null pointer");
+  if (rows < 0 || dim < 1 || ldx < dim || ldo < dim) return fail(nullptr, XV_ERR_INVALID, "xv_length_normalize: bad dimensions");
+  DeviceGuard g(device);
+  if (!g.ok) return fail(nullptr, XV_ERR_HIP, "cannot select HIP device %d", device);
+  const hipError_t e = launch_length_norm(x_dev, ldx, rows, dim, scaleup, out_dev, ldo, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(nullptr, XV_ERR_HIP, "length_norm launch failed: %s", hipGetErrorString(e));
+  return XV_OK;
+}
+
+int xv_speaker_mean(int device, const float* x_dev, int64_t ldx, int dim, const int32_t* spk_offsets_dev,
+                    const int32_t* utt_index_dev, int64_t num_speakers, float* out_dev, int64_t ldo, void* stream) {
+  if (!x_dev || !out_dev || !spk_offsets_dev || !utt_index_dev) return fail(nullptr, XV_ERR_INVALID, "xv_speaker_mean: null pointer");
+  if (num_speakers < 0 || dim < 1 || ldx < dim || ldo < dim) return fail(nullptr, XV_ERR_INVALID, "xv_speaker_mean: bad dimensions");
+  DeviceGuard g(device);
+  if (!g.ok) return fail(nullptr, XV_ERR_HIP, "cannot select HIP device %d", device);
+  const hipError_t e = launch_speaker_mean(x_dev, ldx, dim, spk_offsets_dev, utt_index_dev, num_speakers, out_dev, ldo,
+                                           static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(nullptr, XV_ERR_HIP, "speaker_mean launch failed: %s", hipGetErrorString(e));
+  return XV_OK;
+}
+
 void xv_destroy(xv_handle* h) {
   if (!h) return;
   {

@@ -28,8 +28,10 @@ log = logging.getLogger("xvec.extract")
 def build_parser():
     parser = argparse.ArgumentParser()
     parser.add_argument("-g", "--gpu", type=int, default=-1,
-                        help="The GPU id.  -1 (the reference's 'GPU disabled') selects LOCAL_RANK or device 0: "
-                             "this implementation has no CPU path.")
+                        help="The GPU id.  -1 (the reference's 'GPU disabled'; what run_extract_embeddings.sh passes to "
+                             "every one of its nj jobs) picks a device for this job: (JOB-1) mod visible GPUs when the job "
+                             "index can be read off the specifiers (xvector.JOB.ark / splitN/JOB/), else LOCAL_RANK, "
+                             "else 0.  This implementation has no CPU path.")
     parser.add_argument("-m", "--min-chunk-size", type=int, default=25,
                         help="The minimum length of the segments. Any segment shorted than this value will be ignored.")
     parser.add_argument("-s", "--chunk-size", type=int, default=10000,
@@ -41,6 +43,9 @@ def build_parser():
     parser.add_argument("--batch-frames", type=int, default=76800,
                         help="Frames packed into one device batch (extension; 76800 = 256 utterances x 300 frames).")
     parser.add_argument("--precision", type=str, default="", help="f32 | bf16x3 (extension; default: library default)")
+    parser.add_argument("--scp-input", action="store_true",
+                        help="Accept `scp:<file>` as the rspecifier and read its records natively by seeking (extension; "
+                             "the reference refuses scp input, extract.py:59-61, because Kaldi binaries expand it upstream).")
     parser.add_argument("--python-reader", action="store_true",
                         help="Parse the ark with the pure-Python reader instead of the native batch reader (extension).")
     parser.add_argument("--cmn-window", type=int, default=0,
@@ -160,11 +165,52 @@ def extract_stream(embed_fn, items, write_fn, min_chunk_size=25, chunk_size=1000
     return done, counters["skipped"]
 
 
+def auto_device(rspecifier, wspecifier, device_count=None, environ=None):
+    """Device of a job started with `--gpu -1`.  The reference's launcher gives every job `--gpuid -1`
+    (run_extract_embeddings.sh:68-71) and run.pl substitutes the job index only into the specifier strings
+    (`.../split8/3/feats.scp`, `xvector.3.ark`), so that is where it is read from; jobs then spread over the
+    visible GPUs instead of all landing on device 0."""
+    import re
+    environ = os.environ if environ is None else environ
+    if device_count is None:
+        import torch
+        device_count = torch.cuda.device_count()        # does not initialise the GPU
+    device_count = max(int(device_count), 1)
+    for spec, pat in ((wspecifier, r"xvector\.(\d+)\.(?:ark|scp)"), (rspecifier, r"/split\d+[a-z]*/(\d+)/"),
+                      (wspecifier, r"\.(\d+)\.ark")):
+        m = re.search(pat, spec or "")
+        if m:
+            return (int(m.group(1)) - 1) % device_count
+    if "LOCAL_RANK" in environ:
+        return int(environ["LOCAL_RANK"]) % device_count
+    return 0
+
+
+def _vad_records(vad_rspecifier):
+    """(key, vector) stream of a VAD table (`ark:` / `scp:`), parsed in batches by the native reader (float-vector
+    records arrive as [dim, 1] matrices); .gz and text tables go through the Python reader."""
+    spec = vad_rspecifier.strip()
+    plain = spec.split(":", 1)[-1].strip()
+    if plain.endswith(".gz"):
+        from .kaldi_io import read_vec_flt_ark
+        for kv in read_vec_flt_ark(vad_rspecifier):
+            yield kv
+        return
+    from . import native_ark
+    reader = native_ark.ArkBatchReader(vad_rspecifier, batch_frames=1 << 20, min_frames=0, capacity=(1 << 20) + (1 << 18))
+    try:
+        for keys, offsets, data in reader:
+            flat = data.reshape(-1).copy()
+            for i, k in enumerate(keys):
+                yield k, flat[offsets[i]:offsets[i + 1]]
+    finally:
+        reader.close()
+
+
 def _vad_lookup(vad_rspecifier):
-    """Lock-step lookup in a VAD vector ark that is in the same key order as the features (Kaldi's `scp,s,cs`
+    """Lock-step lookup in a VAD vector table that is in the same key order as the features (Kaldi's `scp,s,cs`
     contract of select-voiced-frames): returns f(key) -> vector, skipping VAD entries without features."""
-    from .kaldi_io import read_vec_flt_ark
-    it = iter(read_vec_flt_ark(vad_rspecifier))
+    it = iter(_vad_records(vad_rspecifier))
 
     def lookup(key):
         for k, v in it:
@@ -174,7 +220,7 @@ def _vad_lookup(vad_rspecifier):
     return lookup
 
 
-def run_native(trainer, rspecifier, fp_out, min_chunk_size, chunk_size, normalize, batch_frames, cmn_window=0,
+def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normalize, batch_frames, cmn_window=0,
                vad_rspecifier=""):
     """Fast path of the driver: the native batch reader (csrc/ark_io.cpp) parses ark records straight into
     pinned staging buffers on a background thread (outside the GIL) while this thread runs the device and
@@ -230,7 +276,7 @@ def run_native(trainer, rspecifier, fp_out, min_chunk_size, chunk_size, normaliz
                     emb = trainer.predict_packed(dev, offsets).cpu().numpy()
                 if normalize:
                     emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
-                fp_out.write(native_ark.format_vectors(keys, emb))
+                writer.write(keys, emb)
                 done += len(keys)
                 continue
         lens = np.diff(offsets)
@@ -239,7 +285,7 @@ def run_native(trainer, rspecifier, fp_out, min_chunk_size, chunk_size, normaliz
             out = []
             extract_stream(trainer.predict_list, iter(items), lambda k, v: out.append((k, v)), min_chunk_size,
                            chunk_size, normalize, batch_frames, prefetch=0)
-            fp_out.write(native_ark.format_vectors([k for k, _ in out], np.stack([v for _, v in out])))
+            writer.write([k for k, _ in out], np.stack([v for _, v in out]))
             done += len(out)
             continue
         host = torch.from_numpy(feats)                  # view of the pinned staging buffer
@@ -248,7 +294,7 @@ def run_native(trainer, rspecifier, fp_out, min_chunk_size, chunk_size, normaliz
             emb = trainer.predict_packed(dev, offsets).cpu().numpy()
         if normalize:
             emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
-        fp_out.write(native_ark.format_vectors(keys, emb))
+        writer.write(keys, emb)
         done += len(keys)
     skipped = reader.skipped + extra_skipped
     reader.close()
@@ -269,35 +315,57 @@ def main(argv=None):
     with open(os.path.join(nnet_dir, "feature_dim"), "r") as f:
         dim = int(f.readline().strip())
 
+    spec = args.rspecifier.strip()
+    if spec.rsplit(".", 1)[-1] == "scp" and not (args.scp_input and spec.startswith(("scp:", "scp,"))):   # extract.py:59-61
+        sys.exit("The rspecifier must be ark or input pipe")
+
     from .trainer import Trainer
-    device = args.gpu if args.gpu >= 0 else None
+    device = args.gpu if args.gpu >= 0 else auto_device(args.rspecifier, args.wspecifier)
+    log.info("Using HIP device %d" % device)
     trainer = Trainer(params, args.model_dir, dim, single_cpu=True, device=device, precision=args.precision or None)
     trainer.build("predict")
 
-    if args.rspecifier.rsplit(".", 1)[-1] == "scp":          # extract.py:59-61
-        sys.exit("The rspecifier must be ark or input pipe")
-
-    fp_out = open_or_fd(args.wspecifier, "wb")
-    plain = args.rspecifier.split(":", 1)[-1].strip()
+    from . import native_ark
+    writer = native_ark.VectorWriter(args.wspecifier)
+    plain = spec.split(":", 1)[-1].strip()
     frontend = args.cmn_window > 0 or bool(args.vad_rspecifier)
-    if frontend and (args.python_reader or plain.endswith(".gz")):
-        sys.exit("--cmn-window / --vad-rspecifier need the native reader (plain ark or pipe input)")
-    if not args.python_reader and not plain.endswith(".gz"):
-        done, skipped = run_native(trainer, args.rspecifier, fp_out, args.min_chunk_size, args.chunk_size,
+    native = not args.python_reader and not plain.endswith(".gz")
+    if native and not plain.endswith("|") and not spec.startswith(("scp:", "scp,")) and not _binary_ark(plain):
+        log.info("[INFO] %s is not a binary ark: using the Python reader." % plain)
+        native = False                      # text-mode ark: the reference's reader handles it (kaldi_io.py:1056-1068)
+    if frontend and not native:
+        sys.exit("--cmn-window / --vad-rspecifier need the native reader (binary ark, scp or pipe input)")
+    if native:
+        done, skipped = run_native(trainer, args.rspecifier, writer, args.min_chunk_size, args.chunk_size,
                                    args.normalize, args.batch_frames, args.cmn_window, args.vad_rspecifier)
     else:
+        if spec.startswith(("scp:", "scp,")):
+            from .kaldi_io import read_mat_scp
+            items = read_mat_scp(plain)
+        else:
+            items = read_mat_ark(args.rspecifier)
         done, skipped = extract_stream(
-            trainer.predict_list, read_mat_ark(args.rspecifier),
-            lambda key, vec: write_vec_flt(fp_out, vec, key=key),
+            trainer.predict_list, items, lambda key, vec: writer.write([key], vec[None, :]),
             min_chunk_size=args.min_chunk_size, chunk_size=args.chunk_size, normalize=args.normalize,
             batch_frames=args.batch_frames)
-    fp_out.close()
-    proc = getattr(fp_out, "_xv_proc", None)
-    if proc is not None:
-        proc.wait()
+    rc = writer.close()
     trainer.close()
     log.info("Extracted %d embeddings (%d utterances skipped)." % (done, skipped))
+    if rc != 0:
+        log.error("the output command of %s exited with code %d" % (args.wspecifier, rc))
+        return 1
     return 0
+
+
+def _binary_ark(path):
+    """True when the first record of the file carries the binary marker `\\0B` after its key."""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(4096)
+    except OSError:
+        return True                         # let the reader report the real error
+    sp = head.find(b" ")
+    return sp < 0 or head[sp + 1:sp + 3] == b"\0B" or len(head) < sp + 3
 
 
 if __name__ == "__main__":

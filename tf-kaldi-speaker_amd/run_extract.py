@@ -1,0 +1,310 @@
+"""Multi-GPU extraction launcher: the counterpart of egs/voxceleb/v1/nnet/run_extract_embeddings.sh.
+
+Same options, positional arguments, stages and output files as the reference script
+(`run_extract_embeddings.sh [--nj N] [--use-gpu B] [--cmd C] [--min-chunk-size 50] [--chunk-size 10000]
+[--stage 0] [--normalize false] [--checkpoint -1] [--env E] [--node output] <nnet-dir> <data> <embeddings-dir>`),
+none of its Kaldi binaries:
+
+  :43     utils/split_data.sh $data $nj            -> utterances sharded over the jobs by frame count (longest
+                                                      processing time first, sharding.lpt_shards) instead of evenly by
+                                                      speaker: a job is a GPU here and finishes when its frames are done
+  :47     apply-cmvn-sliding | select-voiced-frames -> the GPU front-end inside each job (extract.py --cmn-window 300
+                                                      --vad-rspecifier scp:...)
+  :56-59  make_checkpoint.py                       -> set_checkpoint() below (misc/utils.py:251-304)
+  :68-71  run.pl JOB=1:nj extract_wrapper.sh       -> one FRESH process per job, job j on GPU (j-1) mod #GPUs, log in
+                                                      $dir/log/extract.JOB.log, output xvector.JOB.{ark,scp}
+  :75-78  cat xvector.$j.scp > xvector.scp         -> merged back into the order of $data/feats.scp
+  :80-95  ivector-mean (+ ivector-normalize-length) -> postprocess.stage_speaker_mean (GPU)
+  :97-103 ivector-normalize-length                 -> postprocess.stage_length_norm (GPU)
+
+No collective and no inter-GPU traffic anywhere: utterances are independent.  This process never
+touches a GPU before its children have finished (stages 2-3 initialise one afterwards).
+"""
+import argparse
+import os
+import re
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+from . import sharding
+
+
+def _bool(s):
+    if isinstance(s, bool):
+        return s
+    if s.lower() in ("true", "1", "yes"):
+        return True
+    if s.lower() in ("false", "0", "no"):
+        return False
+    raise argparse.ArgumentTypeError("expected true or false, got %r" % s)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="run_extract_embeddings",
+                                usage="%(prog)s [options] <nnet-dir> <data> <embeddings-dir>")
+    # the reference's options (run_extract_embeddings.sh:3-12), Kaldi parse_options style (--name value)
+    p.add_argument("--nj", type=int, default=0, help="number of jobs (reference default 32; here 0 = one per visible GPU)")
+    p.add_argument("--use-gpu", "--use_gpu", type=_bool, default=True, help="accepted for compatibility: the path always runs on GPUs")
+    p.add_argument("--cmd", type=str, default="run.pl", help="accepted for compatibility: jobs are local processes")
+    p.add_argument("--min-chunk-size", "--min_chunk_size", type=int, default=50)
+    p.add_argument("--chunk-size", "--chunk_size", type=int, default=10000)
+    p.add_argument("--stage", type=int, default=0)
+    p.add_argument("--normalize", type=_bool, default=False)
+    p.add_argument("--checkpoint", type=str, default="-1")
+    p.add_argument("--env", type=str, default="", help="accepted for compatibility (conda environment of the reference)")
+    p.add_argument("--node", type=str, default="output")
+    # extensions
+    p.add_argument("--gpus", type=str, default="", help="comma-separated device ids to use (default: all visible)")
+    p.add_argument("--cmn-window", "--cmn_window", type=int, default=300, help="sliding CMN window of the front-end (0 = features are already normalised)")
+    p.add_argument("--apply-vad", "--apply_vad", type=_bool, default=True, help="select voiced frames with $data/vad.scp")
+    p.add_argument("--batch-frames", "--batch_frames", type=int, default=76800)
+    p.add_argument("--precision", type=str, default="")
+    p.add_argument("--job-module", type=str, default="tf_kaldi_speaker_amd.extract", help=argparse.SUPPRESS)
+    p.add_argument("nnetdir")
+    p.add_argument("data")
+    p.add_argument("dir")
+    return p
+
+
+# ------------------------------------------------------------------------------------------ checkpoint
+def set_checkpoint(nnet_dir, checkpoint="-1"):
+    """misc/utils.py:251-304 (get_checkpoint): point <nnet_dir>/checkpoint at the chosen step.  "last" = the newest
+    saved step, -1 = the step of the epoch with the lowest valid_loss ((epoch + 1) * num_steps_per_epoch), any other
+    integer = that step.  Returns the checkpoint path."""
+    state = os.path.join(nnet_dir, "checkpoint")
+    if not os.path.isfile(state):
+        sys.exit("[ERROR] Cannot find checkpoint in %s." % nnet_dir)
+    current, all_paths = None, []
+    with open(state) as f:
+        for line in f:
+            m = re.match(r'\s*(model_checkpoint_path|all_model_checkpoint_paths):\s*"(.*)"', line)
+            if m and m.group(1) == "model_checkpoint_path":
+                current = m.group(2)
+            elif m:
+                all_paths.append(m.group(2))
+    if not current:
+        sys.exit("[ERROR] Cannot read checkpoint %s." % state)
+    if not all_paths:
+        all_paths = [current]
+    steps = sorted(int(c.rsplit("-", 1)[1]) for c in all_paths)
+    if checkpoint == "last":
+        step = steps[-1]
+    else:
+        step = int(checkpoint)
+        if step == -1:
+            loss_file = os.path.join(nnet_dir, "valid_loss")
+            if not os.path.isfile(loss_file):
+                if len(steps) == 1:          # a model directory with one checkpoint and no training history
+                    step = steps[0]
+                else:
+                    sys.exit("[ERROR] --checkpoint -1 needs %s to pick the best model." % loss_file)
+            else:
+                min_epoch, min_loss = -1, 1e10
+                with open(loss_file) as f:
+                    for line in f:
+                        if not line.strip():
+                            continue
+                        epoch, loss = line.split(" ")[:2]
+                        if float(loss) < min_loss:
+                            min_loss, min_epoch = float(loss), int(epoch)
+                from .params import Params
+                params = Params(os.path.join(nnet_dir, "config.json"))
+                step = (min_epoch + 1) * params.num_steps_per_epoch
+    assert step in steps, "The checkpoint %d not in the model directory" % step
+    path = os.path.join(nnet_dir, os.path.basename(current.rsplit("-", 1)[0] + "-" + str(step)))
+    with open(state, "w") as f:
+        f.write('model_checkpoint_path: "%s"\n' % path)
+        for c in all_paths:
+            f.write('all_model_checkpoint_paths: "%s"\n' % os.path.join(nnet_dir, os.path.basename(c)))
+    return path
+
+
+# ------------------------------------------------------------------------------------------ sharding
+def read_table(path):
+    out = []
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if line.strip():
+                key, rest = line.split(None, 1)
+                out.append((key, rest.strip()))
+    return out
+
+
+def make_shards(data_dir, out_dir, nj, use_vad=True, lengths=None):
+    """Shard $data/feats.scp (and vad.scp) over nj jobs by frame count (LPT), each shard in table order.
+    Writes $out_dir/split<nj>/<JOB>/{feats.scp,vad.scp}; returns (keys, lengths, shards)."""
+    feats = read_table(os.path.join(data_dir, "feats.scp"))
+    keys = [k for k, _ in feats]
+    if lengths is None:
+        from . import native_ark
+        lengths = native_ark.scp_lengths(os.path.join(data_dir, "feats.scp"), os.path.join(data_dir, "utt2num_frames"))
+    lengths = np.asarray(lengths, dtype=np.int64)
+    if len(lengths) != len(keys):
+        raise ValueError("feats.scp has %d entries, %d lengths" % (len(keys), len(lengths)))
+    vad = dict(read_table(os.path.join(data_dir, "vad.scp"))) if use_vad else None
+    shards = sharding.lpt_shards(lengths, nj)
+    for j, idx in enumerate(shards):
+        sdir = os.path.join(out_dir, "split%d" % nj, str(j + 1))
+        os.makedirs(sdir, exist_ok=True)
+        with open(os.path.join(sdir, "feats.scp"), "w") as f:
+            for i in idx:
+                f.write("%s %s\n" % feats[i])
+        if vad is not None:
+            with open(os.path.join(sdir, "vad.scp"), "w") as f:
+                for i in idx:
+                    k = keys[i]
+                    if k not in vad:
+                        raise KeyError("utterance %s has no entry in vad.scp" % k)
+                    f.write("%s %s\n" % (k, vad[k]))
+    return keys, lengths, shards
+
+
+# ------------------------------------------------------------------------------------------ jobs
+def job_command(args, job, gpu, sdir):
+    """Command line of job `job` (1-based): the counterpart of
+    `extract_wrapper.sh --gpuid .. --min-chunk-size .. --chunk-size .. --normalize .. --node .. nnetdir feat out`."""
+    cmd = [sys.executable, "-m", args.job_module, "--gpu", str(gpu), "--node", args.node,
+           "--min-chunk-size", str(args.min_chunk_size), "--chunk-size", str(args.chunk_size),
+           "--batch-frames", str(args.batch_frames), "--scp-input"]
+    if args.normalize:
+        cmd.append("--normalize")
+    if args.precision:
+        cmd += ["--precision", args.precision]
+    if args.cmn_window > 0:
+        cmd += ["--cmn-window", str(args.cmn_window)]
+    if args.apply_vad:
+        cmd += ["--vad-rspecifier", "scp:" + os.path.join(sdir, "vad.scp")]
+    cmd += [args.nnetdir, "scp:" + os.path.join(sdir, "feats.scp"),
+            "ark,scp:%s,%s" % (os.path.join(args.dir, "xvector.%d.ark" % job), os.path.join(args.dir, "xvector.%d.scp" % job))]
+    return cmd
+
+
+def run_jobs(commands, logs, slots, env=None, poll=0.05):
+    """Run `commands[i]` (argv lists) as child processes, stdout+stderr to `logs[i]`; `slots[i]` names the resource
+    (GPU) a job occupies: jobs of one slot run one after the other, different slots run concurrently (run.pl
+    JOB=1:nj with one job per GPU at a time).  Returns the list of exit codes."""
+    queues = {}
+    for i, s in enumerate(slots):
+        queues.setdefault(s, []).append(i)
+    running, codes = {}, [None] * len(commands)
+
+    def start(i):
+        os.makedirs(os.path.dirname(logs[i]) or ".", exist_ok=True)
+        fh = open(logs[i], "w")
+        fh.write("# %s\n" % " ".join(commands[i]))
+        fh.flush()
+        running[i] = (subprocess.Popen(commands[i], stdout=fh, stderr=subprocess.STDOUT, env=env), fh)
+
+    for s, q in queues.items():
+        start(q.pop(0))
+    while running:
+        for i in list(running):
+            proc, fh = running[i]
+            rc = proc.poll()
+            if rc is None:
+                continue
+            fh.close()
+            del running[i]
+            codes[i] = rc
+            q = queues[slots[i]]
+            if q:
+                start(q.pop(0))
+        if running:
+            time.sleep(poll)
+    return codes
+
+
+def combine_scp(out_dir, nj, keys):
+    """run_extract_embeddings.sh:75-78 (`cat xvector.$j.scp > xvector.scp`), with the lines put back into the order
+    of $data/feats.scp (the LPT shards interleave the table).  Returns the number of lines."""
+    entry = {}
+    for j in range(1, nj + 1):
+        path = os.path.join(out_dir, "xvector.%d.scp" % j)
+        if not os.path.isfile(path):
+            raise IOError("job %d left no %s" % (j, path))
+        for k, rest in read_table(path):
+            entry[k] = rest
+    n = 0
+    with open(os.path.join(out_dir, "xvector.scp"), "w") as f:
+        for k in keys:
+            if k in entry:                   # utterances shorter than --min-chunk-size have no vector
+                f.write("%s %s\n" % (k, entry[k]))
+                n += 1
+    return n
+
+
+def visible_gpus(spec=""):
+    if spec:
+        return [int(x) for x in spec.split(",") if x.strip() != ""]
+    import torch
+    return list(range(torch.cuda.device_count()))        # counting devices does not initialise the GPU
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    print("%s %s" % ("run_extract_embeddings", " ".join(sys.argv[1:] if argv is None else argv)))
+    need = [os.path.join(args.nnetdir, "nnet", "checkpoint"), os.path.join(args.data, "feats.scp")]
+    if args.apply_vad:
+        need.append(os.path.join(args.data, "vad.scp"))
+    for f in need:
+        if not os.path.isfile(f):
+            print("No such file %s" % f)
+            return 1
+    os.makedirs(os.path.join(args.dir, "log"), exist_ok=True)
+    gpus = visible_gpus(args.gpus)
+    if not gpus:
+        print("run_extract_embeddings: no HIP device visible (the extraction path has no CPU fallback)")
+        return 1
+    nj = args.nj if args.nj > 0 else len(gpus)
+
+    keys = [k for k, _ in read_table(os.path.join(args.data, "feats.scp"))]
+    if args.stage <= 0:
+        print("run_extract_embeddings: extracting xvectors from nnet")
+        print("run_extract_embeddings: embedding from node %s" % args.node)
+        ckpt = set_checkpoint(os.path.join(args.nnetdir, "nnet"), args.checkpoint)
+        print("Set the checkpoint to %s" % ckpt)
+        keys, lengths, shards = make_shards(args.data, args.dir, nj, use_vad=args.apply_vad)
+        load = [int(lengths[s].sum()) for s in shards]
+        print("run_extract_embeddings: %d utterances, %d frames over %d jobs on %d GPU(s); frames per job %s"
+              % (len(keys), int(lengths.sum()), nj, len(gpus), load))
+        cmds, logs, slots = [], [], []
+        for j in range(1, nj + 1):
+            gpu = gpus[(j - 1) % len(gpus)]
+            cmds.append(job_command(args, j, gpu, os.path.join(args.dir, "split%d" % nj, str(j))))
+            logs.append(os.path.join(args.dir, "log", "extract.%d.log" % j))
+            slots.append(gpu)
+        env = dict(os.environ)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        t0 = time.time()
+        codes = run_jobs(cmds, logs, slots, env=env)
+        bad = [j + 1 for j, c in enumerate(codes) if c != 0]
+        if bad:
+            print("run_extract_embeddings: job(s) %s failed; see %s" % (bad, os.path.join(args.dir, "log")))
+            return 1
+        print("run_extract_embeddings: %d jobs finished in %.1f s" % (nj, time.time() - t0))
+    if args.stage <= 1:
+        print("run_extract_embeddings: combining xvectors across jobs")
+        n = combine_scp(args.dir, nj, keys)
+        print("run_extract_embeddings: %d xvectors in %s" % (n, os.path.join(args.dir, "xvector.scp")))
+    if args.stage <= 2:
+        print("run_extract_embeddings: computing mean of xvectors for each speaker")
+        if args.normalize:
+            print("run_extract_embeddings:   Normalize xvectors before computing the mean.")
+        from . import postprocess
+        if not os.path.isfile(os.path.join(args.data, "spk2utt")):
+            print("No such file %s" % os.path.join(args.data, "spk2utt"))
+            return 1
+        postprocess.stage_speaker_mean(args.data, args.dir, args.normalize, device=gpus[0])
+    if args.stage <= 3 and args.normalize:
+        from . import postprocess
+        postprocess.stage_length_norm(args.dir, device=gpus[0])
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
