@@ -8,16 +8,25 @@ the same per-GPU batch on its own GPU (utterances shard with no exchange step ->
 scaling, no collective on the data path; torch.distributed is used for the timing barrier
 and the max-over-ranks only).
 
-Prints ONE JSON line on rank 0 (contract in the task statement), carrying
+Prints ONE JSON line on rank 0 (contract in the task statement).  `value` is the config-2 rate above; beside it
   roofline     : dominant kernel (tdnn3_conv GEMM), algorithmic FLOPs / hipEvent-measured
                  mean launch duration inside the timed region, against the dense MFMA peak;
-  cpu_baseline : oracle/ref_torch.py (fp32 torch-CPU restatement, 1 thread, batch 1 --
-                 mirrors model/trainer.py:135-139 + extract.py:89) on a bounded sample.
+  cpu_baseline : the CPU stand-in of the reference's extraction job (oracle/cpu_extract.py: ark -> ark,
+                 1 thread, batch 1) run as nj = min(host cores, 32) fresh processes side by side
+                 (run_extract_embeddings.sh:3,68) for a bounded time; N = 1 only;
+  value_reps   : min / median / max of 5 more repetitions of the same K-step timed region;
+  e2e_value    : host numpy -> pinned staging -> H2D -> kernels -> D2H (Trainer.predict_list), N = 1 only;
+  cli          : ark -> ark through the command-line driver in a fresh process, N = 1 only;
+  config4      : BASELINE configs[3] / SURVEY 8(d) config 4 -- a FIXED set of 8192 utterances, T ~ U[200,1000]
+                 (seed 2024), LPT-sharded over WORLD_SIZE ranks, resident in HBM, ragged batches; utt/s and
+                 frames/s of the whole set (strong scaling), frames per rank.  Runs at every N.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -43,9 +52,16 @@ def parse_args():
     ap.add_argument("--pooling", default="statistics_pooling", choices=["statistics_pooling", "self_attention"])
     ap.add_argument("--network", default="tdnn", choices=["tdnn", "extended_tdnn", "resnet_18"],
                     help="tdnn = BASELINE configs 1-4; resnet_18 = config 5 (use --dim 40 --batch 64)")
-    ap.add_argument("--varlen", action="store_true", help="config 4: T ~ U[200,1000] (seed 2024)")
+    ap.add_argument("--varlen", action="store_true", help="T ~ U[200,1000] per-GPU batch (config-4 shape as the main workload)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-nj", type=int, default=0, help="processes of the cpu_baseline leg (0 = min(host cores, 32))")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent timing")
+    ap.add_argument("--no-extra", action="store_true", help="only the main timed region (no reps / e2e / cli / config4 legs)")
+    ap.add_argument("--reps", type=int, default=5, help="extra repetitions of the timed region (value_reps)")
+    ap.add_argument("--c4-utts", type=int, default=8192, help="config 4: size of the fixed utterance set")
+    ap.add_argument("--c4-steps", type=int, default=3, help="config 4: timed passes over the set")
+    ap.add_argument("--c4-batch-frames", type=int, default=153600, help="config 4: frames per ragged device batch")
+    ap.add_argument("--cli-utts", type=int, default=65536, help="cli leg: utterances in the ark")
     ap.add_argument("--graph", action="store_true",
                     help="replay the forward from a captured hipGraph (per-kernel events are then not recorded)")
     return ap.parse_args()
@@ -70,28 +86,174 @@ def pmc_traffic(kernel, precision, args):
     return None
 
 
-def cpu_baseline(weights, params, dim, frames, budget_s):
-    """oracle/ref_torch.py on this box's host cores: 1 thread, 1 utterance per call."""
-    import torch
-    from oracle import ref_torch
-    from tf_kaldi_speaker_amd import synth
-    prev = torch.get_num_threads()
-    torch.set_num_threads(1)
+# ------------------------------------------------------------------------------------------ CPU baseline
+def host_cores():
+    """Cores this process may use: scheduler affinity, capped by the cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, quota // int(g.read().split()[0])))
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(n, 1)
+
+
+def cpu_model():
     try:
-        model = (ref_torch.TorchResnet18 if params.network_type == "resnet_18" else ref_torch.TorchTdnn)(weights, params)
-        utts = synth.synth_features(4, frames, dim, seed=99)
-        model.predict(utts[0], dim)                       # warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
-            model.predict(utts[n % len(utts)], dim)
-            n += 1
-            el = time.perf_counter() - t0
-            if el >= budget_s or n >= 2000:
-                break
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def write_feature_ark(path, n, frames, dim, seed=0):
+    """n utterances of [frames, dim] float32 as one binary Kaldi matrix ark (windows of one random matrix)."""
+    from tf_kaldi_speaker_amd import kaldi_io
+    base = np.random.RandomState(seed).standard_normal((frames + 64, dim)).astype(np.float32)
+    with open(path, "wb") as f:
+        for i in range(n):
+            kaldi_io.write_mat(f, base[i % 64:i % 64 + frames], key="utt%07d" % i)
+
+
+def cpu_baseline(weights, params, dim, frames, budget_s, nj):
+    """nj fresh single-thread processes of oracle/cpu_extract.py (ark -> ark, batch 1), each for `budget_s` seconds
+    of extraction; all read the same feature ark (a job's CPU time does not depend on which split it reads)."""
+    from tf_kaldi_speaker_amd import model_io
+    nj = nj if nj > 0 else min(host_cores(), 32)           # 32 = the reference's default nj (run_extract_embeddings.sh:3)
+    tmp = tempfile.mkdtemp(prefix="xvcpu_", dir="/tmp")
+    try:
+        model_dir = os.path.join(tmp, "exp")
+        model_io.save_model(model_dir, dict(params.dict), dim, weights, step=1)
+        ark = os.path.join(tmp, "feats.ark")
+        per_job = int(max(64, budget_s * (300.0 if params.network_type != "resnet_18" else 12.0) * 300.0 / max(frames, 1)))
+        write_feature_ark(ark, per_job, frames, dim, seed=99)
+        env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        procs = []
+        t0 = time.perf_counter()
+        for j in range(nj):
+            cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_extract.py"), "--max-seconds", str(budget_s),
+                   "--min-chunk-size", "25", model_dir, "ark:" + ark, "ark:" + os.path.join(tmp, "xvector.%d.ark" % (j + 1))]
+            procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True))
+        recs = []
+        for p in procs:
+            out, err = p.communicate(timeout=budget_s * 4 + 600)
+            if p.returncode != 0:
+                raise RuntimeError("cpu_extract failed: %s" % err[-500:])
+            recs.append(json.loads(out.strip().splitlines()[-1]))
+        wall = time.perf_counter() - t0
     finally:
-        torch.set_num_threads(prev)
-    return {"value": round(n / el, 3), "unit": "utterances/s", "cores": 1, "kind": "port",
-            "sample": "%d utterances of %dx%d, oracle/ref_torch.py fp32, 1 thread, batch 1, %.1f s" % (n, frames, dim, el)}
+        subprocess.call(["rm", "-rf", tmp])
+    n = sum(r["utterances"] for r in recs)
+    el = max(r["seconds"] for r in recs)
+    total = n / el
+    return {"value": round(total, 2), "unit": "utterances/s", "cores": nj, "kind": "port",
+            "value_total": round(total, 2), "value_per_core": round(total / nj, 3), "cpu_model": cpu_model(),
+            "host_cores": host_cores(), "wall_s": round(wall, 1),
+            "sample": "%d processes x 1 thread of oracle/cpu_extract.py (fp32 torch-CPU restatement, ark->ark, batch 1): %d "
+                      "utterances of %dx%d in %.1f s of extraction each (process start-up excluded)" % (nj, n, frames, dim, el)}
+
+
+# ------------------------------------------------------------------------------------------ extra legs
+def cli_leg(weights, params, dim, frames, n_utts, precision):
+    """ark -> ark through `python -m tf_kaldi_speaker_amd.extract` in a fresh process (ark parsing, H2D, kernels, D2H,
+    vector-ark formatting); the ark sits in the page cache."""
+    from tf_kaldi_speaker_amd import model_io
+    tmp = tempfile.mkdtemp(prefix="xvcli_", dir="/tmp")
+    try:
+        model_dir = os.path.join(tmp, "exp")
+        model_io.save_model(model_dir, dict(params.dict), dim, weights, step=1)
+        ark = os.path.join(tmp, "feats.ark")
+        write_feature_ark(ark, n_utts, frames, dim, seed=5)
+        env = dict(os.environ)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        cmd = [sys.executable, "-m", "tf_kaldi_speaker_amd.extract", "--gpu", "0", "--precision", precision, model_dir,
+               "ark:" + ark, "ark:" + os.path.join(tmp, "xvector.ark")]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": r.stderr[-300:]}
+        loop = None
+        for line in r.stderr.splitlines():
+            if line.startswith("Extracted ") and " in " in line:
+                loop = float(line.rsplit(" in ", 1)[1].split()[0])
+        size = os.path.getsize(os.path.join(tmp, "xvector.ark"))
+    finally:
+        subprocess.call(["rm", "-rf", tmp])
+    return {"utterances": n_utts, "wall_s": round(wall, 2), "loop_s": loop,
+            "value": round(n_utts / loop, 1) if loop else None, "value_incl_startup": round(n_utts / wall, 1),
+            "unit": "utterances/s", "out_bytes": size,
+            "note": "value = utterances / time of the driver's read-embed-write loop; value_incl_startup adds process "
+                    "start-up, model upload and the first-touch of the GPU"}
+
+
+def config4_leg(tr, args, dist, world, rank, dev, weights, params):
+    """the fixed 8192-utterance variable-length set, sharded by utterance (LPT on frames)."""
+    import torch
+    from tf_kaldi_speaker_amd import sharding
+    lens = sharding.config4_lengths(n=args.c4_utts)
+    mine, batches = sharding.rank_batches(lens, world, rank, args.c4_batch_frames)
+    feats, offs, outs, host0 = [], [], [], None
+    for bi, b in enumerate(batches):
+        bl = lens[b]
+        off = np.concatenate([[0], np.cumsum(bl)]).astype(np.int32)
+        x = np.random.RandomState(50000 + int(b[0])).standard_normal((int(off[-1]), args.dim)).astype(np.float32)
+        if bi == 0:
+            host0 = x
+        feats.append(torch.from_numpy(x).to(dev))
+        offs.append(off)
+        info = tr.plan_info(off)
+        outs.append(torch.empty((int(info["out_rows"]), int(info["out_cols"])), dtype=torch.float32, device=dev))
+
+    def one_pass():
+        for x, off, o in zip(feats, offs, outs):
+            tr.predict_packed(x, off, out=o)
+
+    def sync_dev():
+        torch.cuda.synchronize(dev)
+
+    one_pass()                                         # warm-up: every geometry planned, every kernel loaded
+    sync_dev()
+    d = dist if world > 1 else None
+    elapsed = sharding.timed_steps(one_pass, args.c4_steps, sync_dev, dist=d, device=dev)
+    emb = torch.cat(outs, dim=0).cpu().numpy()
+    order = np.array([i for b in batches for i in b], dtype=np.int64)
+    full = sharding.gather_in_order(order, emb, len(lens), dist=d)
+    loads = [int(lens[mine].sum())]
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, loads[0])
+        loads = got
+    if rank != 0:
+        return None
+    from oracle import ref_numpy
+    errs = []
+    b0, off0 = batches[0], offs[0]
+    for j in (0, len(b0) // 2, len(b0) - 1):
+        ref = ref_numpy.predict(host0[off0[j]:off0[j + 1]], weights, params, args.dim)
+        got = full[b0[j]]
+        errs.append(float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
+    total_frames = int(lens.sum())
+    return {"workload": "%d utterances, T ~ U[200,1000] seed 2024, %d dims, LPT-sharded over %d GPU(s), ragged batches of <= %d frames"
+                        % (len(lens), args.dim, world, args.c4_batch_frames),
+            "value": round(len(lens) * args.c4_steps / elapsed, 1), "unit": "utterances/s",
+            "frames_per_s": round(total_frames * args.c4_steps / elapsed, 1), "scaling": "strong", "n_gpus": world,
+            "steps": args.c4_steps, "ms_per_pass": round(elapsed / args.c4_steps * 1e3, 3),
+            "frames_per_rank": loads, "batches_rank0": len(batches), "parity_rel_l2_max": max(errs),
+            "checksum": float(np.sum(full.astype(np.float64)))}
 
 
 def main():
@@ -147,6 +309,7 @@ def main():
     out = torch.empty((int(info["out_rows"]), int(info["out_cols"])), dtype=torch.float32, device=dev)
 
     from tf_kaldi_speaker_amd import sharding
+    d = dist if world > 1 else None
 
     def sync_dev():
         torch.cuda.synchronize(dev)
@@ -168,21 +331,39 @@ def main():
     if not args.no_profile:
         tr.profile_begin(max_events=2 * 48 * (args.steps + 1))
     # barrier + synchronize, exactly K steps, barrier + synchronize, max over ranks
-    elapsed = sharding.timed_steps(step, args.steps, sync_dev, dist=dist if world > 1 else None, device=dev)
+    elapsed = sharding.timed_steps(step, args.steps, sync_dev, dist=d, device=dev)
     kernels = []
     if not args.no_profile:
         kernels, _ = tr.profile_end()
-    # extra leg (not `value`): the same K steps replayed from a captured hipGraph
+    emb = out.cpu().numpy() if rank == 0 else None
+    extra = not args.no_extra
+    # extra legs (never `value`): repetitions of the same region, the same K steps replayed from a captured hipGraph
+    reps = []
+    if extra and args.reps > 0:
+        for _ in range(args.reps):
+            reps.append(sharding.timed_steps(step, args.steps, sync_dev, dist=d, device=dev))
     graph_rate = None
-    if graph is None and not args.varlen:
+    if extra and graph is None and not args.varlen:
         g2, _ = tr.capture_graph(feats, offsets, out=out)
         for _ in range(args.warmup):
             g2.replay()
-        el2 = sharding.timed_steps(g2.replay, args.steps, sync_dev, dist=dist if world > 1 else None, device=dev)
+        el2 = sharding.timed_steps(g2.replay, args.steps, sync_dev, dist=d, device=dev)
         graph_rate = n_gpus * args.batch * args.steps / el2
+        del g2
+    tdnn_default = args.network == "tdnn" and args.pooling == "statistics_pooling"
+    c4 = None
+    if extra and tdnn_default and args.c4_steps > 0:
+        c4 = config4_leg(tr, args, dist, world, rank, dev, weights, params)
+    e2e_rate = None
+    if extra and n_gpus == 1 and rank == 0:
+        tr.predict_list(utts)                              # warm-up (pinned staging buffer)
+        n_e2e = max(2, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(n_e2e):
+            tr.predict_list(utts)
+        e2e_rate = args.batch * n_e2e / (time.perf_counter() - t0)
     result = None
     if rank == 0:
-        emb = out.cpu().numpy()
         total_utts = n_gpus * args.batch * args.steps
         value = total_utts / elapsed
         # parity spot check against the float64 oracle on a few utterances of this batch
@@ -229,15 +410,28 @@ def main():
                         for k in kernels],
             "roofline": roof,
         }
-        if args.cpu_seconds > 0 and n_gpus == 1:
-            result["cpu_baseline"] = cpu_baseline(weights, params, args.dim, args.frames, args.cpu_seconds)
-        else:
-            result["cpu_baseline"] = None
+        if reps:
+            rates = sorted(total_utts / r for r in reps)
+            result["value_reps"] = {"n": len(rates), "min": round(rates[0], 1), "median": round(rates[len(rates) // 2], 1),
+                                    "max": round(rates[-1], 1), "what": "repetitions of the same %d-step timed region" % args.steps}
+        result["e2e_value"] = round(e2e_rate, 1) if e2e_rate else None
+        result["config4"] = c4
     tr.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        torch.cuda.synchronize(dev)
+        result["cli"] = None
+        if extra and n_gpus == 1 and tdnn_default and not args.varlen and args.cli_utts > 0:
+            try:
+                result["cli"] = cli_leg(weights, params, args.dim, args.frames, args.cli_utts, precision)
+            except Exception as e:              # the extra leg must not cost the bench line
+                result["cli"] = {"error": str(e)[:300]}
+        if args.cpu_seconds > 0 and n_gpus == 1:
+            result["cpu_baseline"] = cpu_baseline(weights, params, args.dim, args.frames, args.cpu_seconds, args.cpu_nj)
+        else:
+            result["cpu_baseline"] = None
         print(json.dumps(result))
 
 

@@ -21,9 +21,13 @@
  * with no handle (xv_create) pass NULL.
  *
  * Threading: a handle may be shared by threads for xv_plan_* calls; concurrent
- * xv_forward calls on one handle need distinct workspaces and distinct streams.
- * xv_forward only enqueues work on `stream` and returns (no host synchronisation, no
- * allocation: it may be captured into a hipGraph).
+ * xv_forward calls on one handle need distinct plans, distinct workspaces and distinct
+ * streams (the error string and the profiling records are the only state xv_forward
+ * writes on the handle; both are locked).  xv_forward only enqueues work on `stream` and
+ * returns (no host synchronisation, no allocation: it may be captured into a hipGraph).
+ * Stream order is the only ordering the library relies on: a plan's index arrays are filled
+ * on the stream given to xv_plan_create and recycled by xv_plan_destroy, so create, run and
+ * destroy the plans of a handle on ONE stream, or synchronise between streams yourself.
  */
 #ifndef XVEC_HIP_H_
 #define XVEC_HIP_H_
@@ -129,6 +133,12 @@ int xv_set_tensor(xv_handle* h, const char* tf_name, const float* host, const in
  * per-channel BN scale/shift, packs the kernels into the MFMA tile layout and uploads. */
 int xv_finalize(xv_handle* h);
 
+/* Execution options, to be set before the plans they affect are created.  "pool_fusion" (default 1): statistics
+ * pooling fused into the epilogue of the last frame-level layer; "tail_split" (default 1): deterministic K-split of
+ * the last, nearly empty round of GEMM tiles.  Both change only the schedule (results agree to rounding); tests
+ * switch them off to prove which path ran. */
+int xv_set_option(xv_handle* h, const char* name, int value);
+
 /* endpoints[...] key -> node id (model/trainer.py:380 `endpoints[params.embedding_node]`).
  * Returns the id (>= 0) or XV_ERR_INVALID for a name the graph does not define. */
 int xv_node_id(const xv_handle* h, const char* endpoint_name);
@@ -139,8 +149,9 @@ int xv_node_context(const xv_handle* h, int node_id);
 
 /* Batch geometry.  `frame_offsets` (host, B+1 ascending int32, [0] == 0) delimits the B
  * utterances inside the packed feature matrix.  Builds the device-side row maps once, so
- * xv_forward for this geometry is launch-only.  The calls it makes on `stream` are
- * complete when xv_plan_create returns. */
+ * xv_forward for this geometry is launch-only.  The index arrays are filled by work enqueued
+ * on `stream` (no host synchronisation; device buffers are recycled from destroyed plans of the
+ * handle, so a stream of ragged batches costs no hipMalloc / hipFree per batch). */
 int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int node_id, void* stream,
                    xv_plan** out);
 int xv_plan_query(const xv_plan* p, xv_plan_info* info);

@@ -16,14 +16,15 @@
 //   * a temporal convolution stays an "overlapping-row" GEMM: row m of A is the contiguous
 //     run of w*cin/32 blocks that starts at frame m.
 //
-// Three kernels, all on 128x128 workgroup tiles of 256 threads:
-//   gemm_bf16x3_w14p2_kernel  the default (section 3 below): activation slabs by LDS-DMA, weight fragments
-//                             straight into registers two steps ahead, one wave per 32-channel block, counted waits;
-//   gemm_bf16x3_dma_kernel    its predecessor, kept for A/B (XVEC_GEMM_TILE=1) and for the timing ablations
-//                             (XVEC_GEMM_DIAG): both operands by LDS-DMA, one barrier per K step;
-//   gemm_bf16x3_kernel        register-staged fallback for shapes the slab kernels do not take (more than 9 taps):
-//                             LDS rows padded to 144 bytes (conflict-free ds_read_b128), double buffering, one barrier
-//                             per K step, 2x2 waves of 64x64, two workgroups per CU.
+// The product kernel, on 128x128 workgroup tiles of 256 threads:
+//   gemm_bf16x3_w14p2_kernel  activation slabs by LDS-DMA, weight fragments straight into registers two steps
+//                             ahead, one wave per 32-channel block, counted waits (+ its K-split tail form).
+// Lab builds only (-DXV_LAB; tools/ab_variants.sh -- never in the shipped library):
+//   gemm_bf16x3_dma_kernel    its predecessor, the A/B baseline (XVEC_GEMM_TILE=1) and the vehicle of the timing
+//                             ablations (XVEC_GEMM_DIAG, which produce wrong results on purpose): both operands by
+//                             LDS-DMA, one barrier per K step;
+//   gemm_bf16x3_kernel        register-staged form (XVEC_GEMM_TILE=128): LDS rows padded to 144 bytes, double
+//                             buffering, one barrier per K step, 2x2 waves of 64x64, two workgroups per CU.
 #include <cstdlib>
 #include <mutex>
 
@@ -38,6 +39,16 @@ constexpr int TILE_B = BM * ROWB;         // bytes per operand tile
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 }  // namespace
 
+namespace {
+constexpr int DROW = 128;                          // unpadded LDS row
+constexpr int DA_ROWS = 136;                       // 128 + (w-1 <= 8) halo rows, multiple of 8
+constexpr int DA_BYTES = DA_ROWS * DROW;
+constexpr int DB_BYTES = BN * DROW;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+}  // namespace
+
+#ifdef XV_LAB
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs p, int nMt, int nNt) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   char* As = smem3;                  // [2][BM][ROWB]
@@ -139,14 +150,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs p, int nMt
 // Schedule per step (one tap of one channel block): issue the DMA of the next step's weight
 // tile and this step's share of the next slab, read 16 fragments, 24 MFMAs, __syncthreads()
 // (whose vmcnt(0) retires the DMA issued ~800 cycles earlier).
-namespace {
-constexpr int DROW = 128;                          // unpadded LDS row
-constexpr int DA_ROWS = 136;                       // 128 + (w-1 <= 8) halo rows, multiple of 8
-constexpr int DA_BYTES = DA_ROWS * DROW;
-constexpr int DB_BYTES = BN * DROW;
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-}  // namespace
 
 // (A warp-specialised form -- consumer waves + dedicated DMA loader waves -- was measured at 2x SLOWER and
 // removed: profiles/README.md.)
@@ -301,6 +304,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
   // the final barrier of the K loop has retired every LDS read: reuse the tiles as store scratch
   store_wave_tile(p, acc, m0 + wm * 64, n0 + wn * 64, lane, wave, smem3);
 }
+
+#endif  // XV_LAB
 
 // ------------------------------------------------------------------------------------------
 // Default kernel: 128x128 workgroup tile, "weights in registers", 1 x 4 wave layout, counted waits.
@@ -537,18 +542,18 @@ __global__ void bf16x3_tail_reduce_kernel(GemmArgs p, int mt0, int S) {
 #undef XV_GLD
 #undef XV_WAIT2
 
+#ifdef XV_GEMM_TRACE
 namespace {
 long long* g_trace = nullptr;      // debug trace buffer (device), kTraceWgs workgroups x 4 stamps
 int g_trace_wgs = 0;
 constexpr int kTraceWgs = 16384;
 }  // namespace
+#endif
 
 int64_t gemm_bf16x3_tail_plan(int M, int Kpad, int Npad, int w, int* tail_mt, int* splits) {
   *tail_mt = 0;
   *splits = 1;
-  static int enabled = -1;               // XVEC_GEMM_TAIL=0 switches the tail handling off (A/B)
-  if (enabled < 0) { const char* e = getenv("XVEC_GEMM_TAIL"); enabled = e ? atoi(e) : 1; }
-  if (!enabled || w < 1 || w > 9 || (Kpad >> 5) % w != 0) return 0;
+  if (w < 1 || w > 9 || (Kpad >> 5) % w != 0) return 0;          // (switch: xv_set_option "tail_split")
   const int slots = 256 * 3;             // CUs x resident workgroups of the default kernel
   const int nMt = (M + BM - 1) / BM, nNt = Npad / BN, tiles = nMt * nNt, ncb = (Kpad >> 5) / w;
   const int r = tiles % slots;
@@ -566,6 +571,7 @@ int64_t gemm_bf16x3_tail_plan(int M, int Kpad, int Npad, int w, int* tail_mt, in
 hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
   if (a_in.M <= 0) return hipSuccess;
   GemmArgs a = a_in;
+#ifdef XV_GEMM_TRACE
   {
     static int trace_k = -1;
     if (trace_k < 0) { const char* e = getenv("XVEC_TRACE_K"); trace_k = e ? atoi(e) : 0; }
@@ -575,76 +581,88 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
       if (g_trace && wgs <= kTraceWgs) { a.trace = g_trace; g_trace_wgs = wgs; }
     }
   }
-  static int force = -1;        // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA weights, barrier per step; 0 = default
+#endif
   static std::mutex init_mu;    // the attributes are per device; any thread may make the first launch on one
   static bool attr_set[64] = {};
-  static int diag = 0;              // XVEC_GEMM_DIAG: timing-only ablation switches of the LDS-DMA kernel (outputs invalid)
+  const size_t smemw32 = (size_t)2 * DA_BYTES;      // two slabs; the 4 x 8 KB epilogue scratch overlays them
+#ifdef XV_LAB
+  static int force = 0;         // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA weights, barrier per step; 0 = default
+  static int diag = 0;          // XVEC_GEMM_DIAG: timing-only ablation switches of the LDS-DMA kernel (outputs invalid)
   const size_t smem128 = (size_t)4 * TILE_B;
   const size_t smemdma = (size_t)2 * DA_BYTES + 2 * DB_BYTES;
-  const size_t smemw32 = (size_t)2 * DA_BYTES;      // two slabs; the 4 x 8 KB epilogue scratch overlays them
+#endif
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  std::lock_guard<std::mutex> init_lock(init_mu);
-  if (!attr_set[dev & 63]) {
-    const char* e = getenv("XVEC_GEMM_TILE");
-    force = e ? atoi(e) : 0;
-    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
-    if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemdma);
-    if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-    if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-    if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-    if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-    if (r != hipSuccess) return r;
-    const char* e3 = getenv("XVEC_GEMM_DIAG");
-    diag = e3 ? atoi(e3) : 0;
-    attr_set[dev & 63] = true;
+  {
+    std::lock_guard<std::mutex> init_lock(init_mu);
+    if (!attr_set[dev & 63]) {
+      hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+      if (r != hipSuccess) return r;
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+      if (r != hipSuccess) return r;
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+      if (r != hipSuccess) return r;
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+      if (r != hipSuccess) return r;
+#ifdef XV_LAB
+      const char* e = getenv("XVEC_GEMM_TILE");
+      force = e ? atoi(e) : 0;
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
+      if (r != hipSuccess) return r;
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_dma_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemdma);
+      if (r != hipSuccess) return r;
+      const char* e3 = getenv("XVEC_GEMM_DIAG");
+      diag = e3 ? atoi(e3) : 0;
+#endif
+      attr_set[dev & 63] = true;
+    }
   }
   const int w = a.K / a.cin > 0 && a.ldsbx == a.cin ? a.K / a.cin : 1;   // taps (dense: 1)
   const bool taps_ok = w <= 9 && (a.Kpad >> 5) % w == 0;   // slab halo: 128 + w - 1 <= DA_ROWS (136)
-  if (force != 1 && force != 128 && taps_ok) {   // default: 1 x 4 waves, weights in registers two steps ahead
-    const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
-    // tail handling decided at plan time (the plan owns the partial workspace): the last tail_mt M tiles go K-split
-    const bool tail = a.tail_mt > 0 && a.ksplit > 1 && a.partial && !a.a_pitch && !a.pool_part && !a.R && !a.raw &&
-                      a.tail_mt < nMt && (a.N & 3) == 0;
-    const int nMain = tail ? nMt - a.tail_mt : nMt;
-    const dim3 grid(nMain * nNt), block(256);
-    if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
-    if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1>), grid, block, smemw32, s, a, nMain, nNt, w);
-    else        hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4>), grid, block, smemw32, s, a, nMain, nNt, w);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || !tail) return e;
-    const dim3 tgrid(a.tail_mt * nNt * a.ksplit);
-    if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<1>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
-    else        hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<4>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const int64_t total = (int64_t)a.tail_mt * BM * (a.Npad >> 2);
-    hipLaunchKernelGGL(bf16x3_tail_reduce_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, s, a, nMain, a.ksplit);
-    return hipGetLastError();
-  }
-  if (force != 128 && taps_ok) {
-    const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
+  const int nNt = a.Npad / BN, nMt = (a.M + BM - 1) / BM;
+#ifdef XV_LAB
+  if (force == 1 && taps_ok) {
     hipLaunchKernelGGL(gemm_bf16x3_dma_kernel, dim3(nMt * nNt), dim3(256), smemdma, s, a, nMt, nNt, w, diag);
     return hipGetLastError();
   }
-  const int nMt = (a.M + BM - 1) / BM, nNt = a.Npad / BN;
-  hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(nMt * nNt), dim3(256), smem128, s, a, nMt, nNt);
+  if (force == 128 || !taps_ok) {
+    hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(nMt * nNt), dim3(256), smem128, s, a, nMt, nNt);
+    return hipGetLastError();
+  }
+#endif
+  if (!taps_ok) return hipErrorInvalidValue;   // the plan only routes layers of <= 9 taps and whole 32-channel blocks here
+  // 1 x 4 waves, weights in registers two steps ahead.  Tail handling is decided at plan time (the plan owns the
+  // partial workspace): the last tail_mt M tiles go K-split
+  const bool tail = a.tail_mt > 0 && a.ksplit > 1 && a.partial && !a.a_pitch && !a.pool_part && !a.R && !a.raw &&
+                    a.tail_mt < nMt && (a.N & 3) == 0;
+  const int nMain = tail ? nMt - a.tail_mt : nMt;
+  const dim3 grid(nMain * nNt), block(256);
+#ifdef XV_GEMM_TRACE
+  if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
+#endif
+  if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1>), grid, block, smemw32, s, a, nMain, nNt, w);
+  else        hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4>), grid, block, smemw32, s, a, nMain, nNt, w);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || !tail) return e;
+  const dim3 tgrid(a.tail_mt * nNt * a.ksplit);
+  if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<1>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
+  else        hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<4>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int64_t total = (int64_t)a.tail_mt * BM * (a.Npad >> 2);
+  hipLaunchKernelGGL(bf16x3_tail_reduce_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, s, a, nMain, a.ksplit);
   return hipGetLastError();
 }
 
 }  // namespace xv
 
+#ifdef XV_GEMM_TRACE
 // debug only (not part of the public ABI): copy the phase stamps of the last traced GEMM launch
 extern "C" int xvdbg_gemm_trace(long long* out, int max_wgs) {
   if (!xv::g_trace || xv::g_trace_wgs <= 0) return 0;
@@ -653,3 +671,4 @@ extern "C" int xvdbg_gemm_trace(long long* out, int max_wgs) {
   if (hipMemcpy(out, xv::g_trace, sizeof(long long) * 4 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return n;
 }
+#endif

@@ -133,7 +133,16 @@ struct xv_handle {
   int device = 0;
   bool finalized = false;
   std::string err;
-  std::mutex mu;
+  std::mutex mu;                                      // graph / weights / options
+  std::mutex err_mu;                                  // h->err (any thread may fail)
+  std::mutex prof_mu;                                 // profiling records (xv_forward from several threads)
+  // options (xv_set_option)
+  int opt_pool_fusion = 1;                            // statistics pooling fused into the last frame layer's epilogue
+  int opt_tail_split = 1;                             // K-split of the last, nearly empty round of GEMM tiles
+  // device index arrays of destroyed plans, kept for the next plan (no hipMalloc / hipFree per ragged batch)
+  std::mutex pool_mu;
+  std::vector<DevBuf> pool;
+  size_t pool_bytes = 0;
   std::map<std::string, HostTensor> tensors;          // expected variables
   std::vector<Layer> layers;
   std::vector<Value> values;
@@ -198,7 +207,10 @@ int fail(xv_handle* h, int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  if (h) h->err = buf;
+  if (h) {
+    std::lock_guard<std::mutex> lk(h->err_mu);
+    h->err = buf;
+  }
   g_last_error = buf;
   return code;
 }
@@ -212,6 +224,47 @@ int fail(xv_handle* h, int code, const char* fmt, ...) {
   } while (0)
 
 int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// Plan index arrays come from / go back to a per-handle pool: a ragged ark stream creates one plan per batch, and
+// hipMalloc / hipFree (device-synchronising) per batch would serialise the host with the GPU.
+constexpr size_t kPoolMaxBuffers = 96, kPoolMaxBytes = (size_t)1 << 30;
+
+hipError_t pool_take(xv_handle* h, size_t bytes, DevBuf& out) {
+  out = DevBuf();
+  if (bytes == 0) return hipSuccess;
+  {
+    std::lock_guard<std::mutex> lk(h->pool_mu);
+    int best = -1;
+    for (size_t i = 0; i < h->pool.size(); ++i)
+      if (h->pool[i].bytes >= bytes && h->pool[i].bytes <= 4 * bytes + 4096 &&
+          (best < 0 || h->pool[i].bytes < h->pool[best].bytes))
+        best = (int)i;
+    if (best >= 0) {
+      out = h->pool[best];
+      h->pool_bytes -= out.bytes;
+      h->pool.erase(h->pool.begin() + best);
+      return hipSuccess;
+    }
+  }
+  const size_t cap = (bytes + 4095) / 4096 * 4096;
+  const hipError_t e = hipMalloc(&out.p, cap);
+  if (e == hipSuccess) out.bytes = cap; else out = DevBuf();
+  return e;
+}
+
+void pool_give(xv_handle* h, DevBuf& b) {
+  if (!b.p) return;
+  {
+    std::lock_guard<std::mutex> lk(h->pool_mu);
+    if (h->pool.size() < kPoolMaxBuffers && h->pool_bytes + b.bytes <= kPoolMaxBytes) {
+      h->pool.push_back(b);
+      h->pool_bytes += b.bytes;
+      b = DevBuf();
+      return;
+    }
+  }
+  b.release();
+}
 
 uint16_t f32_to_bf16_rn(float f) {   // round to nearest even; inputs are finite weights
   uint32_t u;
@@ -687,7 +740,7 @@ int xv_finalize(xv_handle* h) {
     const bool bf = h->desc.precision == XV_PREC_BF16X3;
     if (L.mode == 0) {
       L.im2col = bf && op.in0 == 0;
-      L.use_split = L.im2col || (bf && vin.frame_level && (L.w == 1 || L.cin % 32 == 0));
+      L.use_split = L.im2col || (bf && vin.frame_level && (L.w == 1 || (L.cin % 32 == 0 && L.w <= 9)));   // slab halo of the split kernel
     } else {      // grid convolutions: whole SB blocks per tap; conv0 goes through its own im2col
       L.use_split = bf && (L.mode == 4 || L.cin % 32 == 0);
     }
@@ -717,6 +770,15 @@ int xv_finalize(xv_handle* h) {
   XV_HIP(h, hipDeviceSynchronize());
   for (auto& kv : h->tensors) { kv.second.data.clear(); kv.second.data.shrink_to_fit(); }
   h->finalized = true;
+  return XV_OK;
+}
+
+int xv_set_option(xv_handle* h, const char* name, int value) {
+  if (!h || !name) return fail(h, XV_ERR_INVALID, "xv_set_option: null argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!strcmp(name, "pool_fusion")) h->opt_pool_fusion = value != 0;
+  else if (!strcmp(name, "tail_split")) h->opt_tail_split = value != 0;
+  else return fail(h, XV_ERR_INVALID, "xv_set_option: unknown option '%s'", name);
   return XV_OK;
 }
 
@@ -837,7 +899,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     int readers = 0;
     for (int o2 : order)
       if (h->ops[o2].in0 == op.in0 || h->ops[o2].in1 == op.in0) ++readers;
-    if (readers == 1 && L.w == 1 && (L.cout & 3) == 0 && !getenv("XVEC_NO_POOL_FUSION")) fused_value = op.in0;
+    if (readers == 1 && L.w == 1 && (L.cout & 3) == 0 && h->opt_pool_fusion) fused_value = op.in0;
   }
   if (fused_value >= 0) {
     const int ctx = h->values[fused_value].ctx;
@@ -890,7 +952,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       } else if (!L.use_split && op.out != fused_value) {
         st.ksplit = gemm_f32_ksplit(st.M, L.Kpad, L.Npad);
         if (st.ksplit > 1) scratch = (int64_t)st.ksplit * st.M * L.Npad * 4;
-      } else if (L.use_split && L.mode == 0 && op.out != fused_value && op.in1 <= 0) {
+      } else if (L.use_split && L.mode == 0 && op.out != fused_value && op.in1 <= 0 && h->opt_tail_split) {
         scratch = gemm_bf16x3_tail_plan(st.M, L.Kpad, L.Npad, L.w, &st.tail_mt, &st.ksplit);
       }
       if (scratch > 0) {
@@ -901,9 +963,13 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       st.stage = st.to_out ? node.stage : 2;
       st.bytes = 8 * st.rows_out * h->values[op.out].cols;
     } else if (op.kind == OP_STAT_POOL || op.kind == OP_ATT_POOL) {
-      if (op.kind == OP_STAT_POOL && op.in0 == fused_value) st.fuse_pool = true;
       st.bytes = 4 * (st.rows_in * h->values[op.in0].cols + st.rows_out * h->values[op.out].cols);
       st.flops = 4 * st.rows_in * h->values[op.in0].cols;
+      if (op.kind == OP_STAT_POOL && op.in0 == fused_value) {      // finalize only: reads the (sum, M2) slots
+        st.fuse_pool = true;
+        st.bytes = 4 * (p->pool_slots * 2 * h->values[op.in0].cols + st.rows_out * h->values[op.out].cols);
+        st.flops = 6 * p->pool_slots * h->values[op.in0].cols;
+      }
     } else if (op.kind == OP_ATT_SCORES) {
       st.bytes = 4 * st.rows_in * h->values[op.in0].cols;
       st.flops = 2 * st.rows_in * (int64_t)h->att_dk_h * h->desc.att_num_heads;
@@ -987,11 +1053,11 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     return rc;
   };
   hipError_t e;
-  if ((e = p->d_offsets.alloc((size_t)(batch + 1) * 4)) != hipSuccess) return bail(e, "hipMalloc(offsets)");
+  if ((e = pool_take(h, (size_t)(batch + 1) * 4, p->d_offsets)) != hipSuccess) return bail(e, "hipMalloc(offsets)");
   if ((e = hipMemcpyAsync(p->d_offsets.p, p->offsets.data(), (size_t)(batch + 1) * 4, hipMemcpyHostToDevice, s)) != hipSuccess)
     return bail(e, "hipMemcpyAsync(offsets)");
   if (rowmap_elems > 0) {
-    if ((e = p->d_rowmaps.alloc((size_t)rowmap_elems * 4)) != hipSuccess) return bail(e, "hipMalloc(rowmaps)");
+    if ((e = pool_take(h, (size_t)rowmap_elems * 4, p->d_rowmaps)) != hipSuccess) return bail(e, "hipMalloc(rowmaps)");
     for (const PlanStep& st : p->steps) {
       if (st.rowmap < 0) continue;
       const Op& op = h->ops[st.op];
@@ -1009,15 +1075,16 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
   if (fused_value >= 0) {
     const int ctx = h->values[fused_value].ctx;
     const int64_t rows = value_rows(h, fused_value, F0, batch);
-    if ((e = p->d_row2utt.alloc((size_t)rows * 4)) != hipSuccess) return bail(e, "hipMalloc(row2utt)");
-    if ((e = p->d_slotbase.alloc((size_t)batch * 4)) != hipSuccess) return bail(e, "hipMalloc(slotbase)");
+    if ((e = pool_take(h, (size_t)rows * 4, p->d_row2utt)) != hipSuccess) return bail(e, "hipMalloc(row2utt)");
+    if ((e = pool_take(h, (size_t)batch * 4, p->d_slotbase)) != hipSuccess) return bail(e, "hipMalloc(slotbase)");
     if ((e = hipMemcpyAsync(p->d_slotbase.p, p->offsets_slotbase.data(), (size_t)batch * 4, hipMemcpyHostToDevice, s)) != hipSuccess)
       return bail(e, "hipMemcpyAsync(slotbase)");
     if ((e = launch_build_row2utt(static_cast<const int32_t*>(p->d_offsets.p), batch, ctx,
                                   static_cast<int32_t*>(p->d_row2utt.p), (int)rows, s)) != hipSuccess)
       return bail(e, "build_row2utt");
   }
-  if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+  // no host synchronisation: the index arrays are filled in stream order, ahead of any xv_forward enqueued on
+  // `stream` afterwards (the host copies they are filled from belong to the plan)
   *out = p;
   return XV_OK;
 }
@@ -1032,10 +1099,10 @@ void xv_plan_destroy(xv_plan* p) {
   if (!p) return;
   {
     DeviceGuard g(p->h->device);
-    p->d_offsets.release();
-    p->d_rowmaps.release();
-    p->d_row2utt.release();
-    p->d_slotbase.release();
+    pool_give(p->h, p->d_offsets);
+    pool_give(p->h, p->d_rowmaps);
+    pool_give(p->h, p->d_row2utt);
+    pool_give(p->h, p->d_slotbase);
   }
   delete p;
 }
@@ -1080,8 +1147,17 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
   const xv_model_desc& d = h->desc;
   const bool split = d.precision == XV_PREC_BF16X3;
 
-  const bool prof = h->profiling && h->prof_next + 2 * p->steps.size() <= h->prof_pool.size();
-  if (prof) h->prof_forwards++;
+  bool prof = false;
+  size_t prof_base = 0;
+  if (h->profiling) {                     // reserve this forward's events under the lock; record them outside it
+    std::lock_guard<std::mutex> lk(h->prof_mu);
+    if (h->profiling && h->prof_next + 2 * p->steps.size() <= h->prof_pool.size()) {
+      prof = true;
+      prof_base = h->prof_next;
+      h->prof_next += 2 * p->steps.size();
+      h->prof_forwards++;
+    }
+  }
 
   for (size_t si = 0; si < p->steps.size(); ++si) {
     const PlanStep& st = p->steps[si];
@@ -1093,8 +1169,8 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
     (void)split;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (prof) {
-      pe0 = h->prof_pool[h->prof_next++];
-      pe1 = h->prof_pool[h->prof_next++];
+      pe0 = h->prof_pool[prof_base + 2 * si];
+      pe1 = h->prof_pool[prof_base + 2 * si + 1];
       XV_HIP(h, hipEventRecord(pe0, s));
     }
     switch (op.kind) {
@@ -1244,6 +1320,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
     }
     if (prof) {
       XV_HIP(h, hipEventRecord(pe1, s));
+      std::lock_guard<std::mutex> lk(h->prof_mu);
       h->prof_recs.push_back({pe0, pe1, p, (int)si});
     }
   }
@@ -1260,6 +1337,7 @@ int xv_profile_begin(xv_handle* h, int max_events) {
   if (!h) return fail(nullptr, XV_ERR_INVALID, "xv_profile_begin: null handle");
   if (max_events < 2) return fail(h, XV_ERR_INVALID, "xv_profile_begin: max_events < 2");
   DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->prof_mu);
   while ((int)h->prof_pool.size() < max_events) {
     hipEvent_t e;
     XV_HIP(h, hipEventCreate(&e));
@@ -1275,9 +1353,10 @@ int xv_profile_begin(xv_handle* h, int max_events) {
 int xv_profile_end(xv_handle* h, xv_kernel_time* entries, int max_entries, int* n_forwards) {
   if (!h) return fail(nullptr, XV_ERR_INVALID, "xv_profile_end: null handle");
   if (!h->profiling) return fail(h, XV_ERR_STATE, "xv_profile_end without xv_profile_begin");
-  h->profiling = false;
   if (!entries || max_entries < 1) return fail(h, XV_ERR_INVALID, "xv_profile_end: no entry buffer");
   DeviceGuard g(h->device);
+  std::lock_guard<std::mutex> lk(h->prof_mu);
+  h->profiling = false;
   int n = 0;
   std::vector<int> count;
   for (const auto& r : h->prof_recs) {
@@ -1355,6 +1434,7 @@ void xv_destroy(xv_handle* h) {
     for (auto& L : h->layers) { L.wt.release(); L.wsb.release(); L.wfr.release(); L.vec.release(); }
     h->query.release();
     h->post_vec.release();
+    for (auto& b : h->pool) b.release();
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   }
   delete h;

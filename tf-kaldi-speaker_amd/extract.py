@@ -335,6 +335,10 @@ def main(argv=None):
         native = False                      # text-mode ark: the reference's reader handles it (kaldi_io.py:1056-1068)
     if frontend and not native:
         sys.exit("--cmn-window / --vad-rspecifier need the native reader (binary ark, scp or pipe input)")
+    import time
+    if trainer.model is not None and os.path.isfile(os.path.join(trainer.model, "checkpoint")):
+        trainer.load()                      # the reference restores lazily inside the first predict (trainer.py:891-895)
+    t_loop = time.perf_counter()
     if native:
         done, skipped = run_native(trainer, args.rspecifier, writer, args.min_chunk_size, args.chunk_size,
                                    args.normalize, args.batch_frames, args.cmn_window, args.vad_rspecifier)
@@ -350,7 +354,7 @@ def main(argv=None):
             batch_frames=args.batch_frames)
     rc = writer.close()
     trainer.close()
-    log.info("Extracted %d embeddings (%d utterances skipped)." % (done, skipped))
+    log.info("Extracted %d embeddings (%d utterances skipped) in %.3f s" % (done, skipped, time.perf_counter() - t_loop))
     if rc != 0:
         log.error("the output command of %s exited with code %d" % (args.wspecifier, rc))
         return 1

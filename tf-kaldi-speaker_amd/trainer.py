@@ -8,6 +8,7 @@ Where the reference builds a TF graph and calls sess.run, this class creates an
 their TensorFlow names and runs the HIP kernels.  PyTorch is used only for device memory
 and the stream.  There is no CPU path: without the HIP library or a GPU this raises.
 """
+import collections
 import ctypes as C
 import os
 import sys
@@ -66,8 +67,12 @@ class Trainer(object):
         self._device_index = int(device)
         self._lib = None
         self._h = None
-        self._plans = {}
+        self._plans = collections.OrderedDict()     # (node, offsets bytes) -> (plan, info), least recently used first
+        self._plan_cache_size = 128
+        self._pinned_plans = set()                    # keys of plans a captured hipGraph refers to: never evicted
         self._ws = None
+        self._ws_pinned = False                       # a captured graph holds the workspace pointer: no regrow
+        self._options = {}
         self._step = None
         self._torch = None
         self._pinned = None
@@ -182,6 +187,8 @@ class Trainer(object):
         h = C.c_void_p()
         _lib.check(self._lib.xv_create(C.byref(desc), self._device_index, C.byref(h)))
         self._h = h
+        for name, value in self._options.items():
+            _lib.check(self._lib.xv_set_option(self._h, name.encode(), value), self._h)
         try:
             unused = []
             for name, arr in weights.items():
@@ -203,10 +210,21 @@ class Trainer(object):
         self.is_loaded = True
 
     # ------------------------------------------------------------------ device-level predict
-    def _plan(self, offsets, node):
+    def set_option(self, name, value):
+        """Execution option of the library (xv_set_option: "pool_fusion", "tail_split"); affects plans created later."""
+        self._options[name] = int(value)
+        if self._h is not None:
+            _lib.check(self._lib.xv_set_option(self._h, name.encode(), int(value)), self._h)
+            for k in [k for k in self._plans if k not in self._pinned_plans]:
+                self._lib.xv_plan_destroy(self._plans.pop(k)[0])
+
+    def _plan(self, offsets, node, pin=False):
         key = (node, offsets.tobytes())
         ent = self._plans.get(key)
         if ent is not None:
+            self._plans.move_to_end(key)
+            if pin:
+                self._pinned_plans.add(key)
             return ent
         nid = self._lib.xv_node_id(self._h, node.encode())
         if nid < 0:
@@ -222,18 +240,37 @@ class Trainer(object):
         _lib.check(rc, self._h)
         info = _lib.PlanInfo()
         _lib.check(self._lib.xv_plan_query(plan, C.byref(info)))
-        if len(self._plans) >= 64:                     # bounded cache of batch geometries
-            _, (old, _) = self._plans.popitem()
-            self._lib.xv_plan_destroy(old)
+        # bounded LRU cache of batch geometries; the device arrays of an evicted plan go back to the library's pool
+        # and are handed to the next plan in stream order (a ragged ark stream makes one plan per batch)
+        while len(self._plans) >= self._plan_cache_size:
+            victim = next((k for k in self._plans if k not in self._pinned_plans), None)
+            if victim is None:
+                break
+            self._lib.xv_plan_destroy(self._plans.pop(victim)[0])
         self._plans[key] = (plan, info)
+        if pin:
+            self._pinned_plans.add(key)
         return plan, info
 
-    def _workspace(self, nbytes):
+    def _workspace(self, nbytes, pin=False):
         torch = self._torch
         if self._ws is None or self._ws.numel() < nbytes:
+            if self._ws_pinned:
+                raise RuntimeError("the workspace is referenced by a captured hipGraph and cannot grow from %d to %d bytes; "
+                                   "capture the largest geometry first or release the graph (Trainer.release_graphs)"
+                                   % (self._ws.numel(), nbytes))
             self._ws = None
-            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda:%d" % self._device_index)
+            # head-room so that a stream of ragged batches of one size class does not regrow it batch after batch
+            self._ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device="cuda:%d" % self._device_index)
+        if pin:
+            self._ws_pinned = True
         return self._ws
+
+    def release_graphs(self):
+        """Declare every hipGraph captured from this trainer dead: their plans may be evicted and the workspace may
+        grow again."""
+        self._pinned_plans.clear()
+        self._ws_pinned = False
 
     def predict_packed(self, feats_dev, offsets, node=None, out=None):
         """Device-resident entry: `feats_dev` is a float32 CUDA tensor [total_frames, ld] holding
@@ -270,8 +307,10 @@ class Trainer(object):
             self._lazy_load()
         node = node or self.embeddings
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)
-        _, info = self._plan(offsets, node)                # plan + workspace exist before the capture starts
-        self._workspace(info.workspace_bytes + 256)
+        # plan + workspace exist before the capture starts, and stay: the graph holds raw pointers to the plan's
+        # device arrays and to the workspace, so the plan is exempt from eviction and the workspace from regrowth
+        _, info = self._plan(offsets, node, pin=True)
+        self._workspace(info.workspace_bytes + 256, pin=True)
         if out is None:
             out = torch.empty((int(info.out_rows), int(info.out_cols)), dtype=torch.float32, device=feats_dev.device)
         self.predict_packed(feats_dev, offsets, node, out=out)         # warm-up outside the capture
@@ -387,7 +426,9 @@ class Trainer(object):
         if self._lib is not None:
             for plan, _ in self._plans.values():
                 self._lib.xv_plan_destroy(plan)
-            self._plans = {}
+            self._plans = collections.OrderedDict()
+            self._pinned_plans = set()
+            self._ws_pinned = False
             if self._h is not None:
                 self._lib.xv_destroy(self._h)
                 self._h = None
