@@ -136,7 +136,8 @@ int xv_finalize(xv_handle* h);
 /* Execution options, to be set before the plans they affect are created.  "pool_fusion" (default 1): statistics
  * pooling fused into the epilogue of the last frame-level layer; "tail_split" (default 1): deterministic K-split of
  * the last, nearly empty round of GEMM tiles.  Both change only the schedule (results agree to rounding); tests
- * switch them off to prove which path ran. */
+ * switch them off to prove which path ran.  "profile_dominant" (default 0): xv_profile_* brackets only the step
+ * with the most algorithmic FLOPs of each plan (two events per forward instead of two per kernel). */
 int xv_set_option(xv_handle* h, const char* name, int value);
 
 /* endpoints[...] key -> node id (model/trainer.py:380 `endpoints[params.embedding_node]`).

@@ -134,6 +134,46 @@ def test_fused_pooling_path_is_taken_at_the_baseline_geometry():
     assert ws_plain > ws_fused                                  # the unfused plan carries the [73216, 1500] activation
 
 
+@pytest.mark.parametrize("kw", [
+    {},                                                                                   # the shipped config: 1 head
+    {"att_num_heads": 3, "att_split_key": False, "att_split_value": False},               # every head pools every channel
+    {"att_num_heads": 5, "num_nodes_pooling_layer": 1600, "att_key_num_nodes": [1500, 1600]},   # split heads of 320 channels
+])
+def test_fused_attention_path_matches_unfused_and_exact(kw):
+    """Attentive pooling with the key / value never stored (score partials in the epilogue of the last key layer,
+    weighted moments in the epilogue of the value layer, model/pooling.py:189-217) against the unfused kernels
+    (xv_set_option "att_fusion" 0) and against the exact fp32 path, on a ragged batch with several M tiles."""
+    from tf_kaldi_speaker_amd import synth
+    import torch
+    params = dict(synth.TDNN_ATT_PARAMS, **kw)
+    weights = synth.synth_weights(params, 30, seed=6)
+    weights["tdnn/attention/query"] = weights["tdnn/attention/query"] * 30.0
+    lens = [300, 64, 200, 15, 129, 333, 78, 500]
+    utts = synth.synth_features(len(lens), lens, 30, seed=21)
+    feats = torch.from_numpy(np.concatenate(utts)).cuda()
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nodes = ("att_output_before_nonlinear", "tdnn6_dense")
+    tr = _trainer(params, weights, 30, "bf16x3")
+    ws_fused = tr.plan_info(offs, "tdnn6_dense")["workspace_bytes"]
+    fused = _run_nodes(tr, feats, offs, nodes)
+    tr.set_option("att_fusion", 0)
+    ws_plain = tr.plan_info(offs, "tdnn6_dense")["workspace_bytes"]
+    plain = _run_nodes(tr, feats, offs, nodes)
+    tr.close()
+    tr = _trainer(params, weights, 30, "f32")
+    exact = _run_nodes(tr, feats, offs, nodes)
+    tr.close()
+    for node in nodes:
+        assert _rel2(fused[node], exact[node]) <= TOL, (node, kw)
+        assert _rel2(plain[node], exact[node]) <= TOL, (node, kw)
+        assert _rel2(fused[node], plain[node]) <= 2e-5, (node, kw)
+    assert not np.array_equal(fused[nodes[0]], plain[nodes[0]])      # a different summation order: the fused path ran
+    assert ws_plain > ws_fused                                        # no [rows, 1500] key / value in the fused plan
+    for i in (0, 3, 7):                                               # and against the float64 oracle
+        ref = ref_numpy.predict(utts[i], weights, params, 30)
+        assert _rel(fused["tdnn6_dense"][i], ref) <= TOL, (i, kw)
+
+
 def test_vmcnt_retires_in_issue_order(tmp_path, repo_root):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):

@@ -349,7 +349,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
 //    (gemm_bf16x3_tail_plan) can run one slice of K per workgroup.
 // The activation fragment addresses use ONE swizzle and ONE row offset per lane ((32*mi + r) >> 1 == r >> 1 mod 8)
 // plus ds_read immediates, which frees the registers for the third weight buffer at 3 workgroups / CU.
-template <int NPS>
+// EPI selects the epilogue at compile time: 0 = activations (fp32 / SB / residual / fused statistics pooling),
+// 1 / 2 = the attention forms of xv_epilogue.h (score partials of the last key layer / weighted moments of the value).
+// A separate instantiation keeps the default kernel's code -- and its register allocation -- untouched.
+template <int NPS, int EPI = 0>
 __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, int w, char* smem3, int cb_begin, int cb_end) {
   char* As = smem3;
   const int tid = threadIdx.x;
@@ -472,16 +475,17 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   stamp(2);
-  store_wave_tile_n32<64>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
+  if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
+  else store_wave_tile_n32<64>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
   stamp(3);
 }
 
-template <int NPS>
+template <int NPS, int EPI = 0>
 __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_kernel(GemmArgs p, int nMt, int nNt, int w) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   const int tile = xcd_remap(blockIdx.x, nMt * nNt);
   const int mt = tile / nNt, nt = tile - mt * nNt;
-  w14p2_tile<NPS>(p, mt * BM, nt * BN, w, smem3, 0, (p.Kpad >> 5) / w);
+  w14p2_tile<NPS, EPI>(p, mt * BM, nt * BN, w, smem3, 0, (p.Kpad >> 5) / w);
 }
 
 // K-split form for the M tiles of the last, nearly empty round (gemm_bf16x3_tail_plan): workgroup = (tile, slice);
@@ -602,6 +606,12 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
       r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
       if (r != hipSuccess) return r;
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+      if (r != hipSuccess) return r;
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+      if (r != hipSuccess) return r;
       r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
       if (r != hipSuccess) return r;
@@ -639,6 +649,12 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
   if (!taps_ok) return hipErrorInvalidValue;   // the plan only routes layers of <= 9 taps and whole 32-channel blocks here
   // 1 x 4 waves, weights in registers two steps ahead.  Tail handling is decided at plan time (the plan owns the
   // partial workspace): the last tail_mt M tiles go K-split
+  if (a.att_part || a.pool_w) {                 // attention epilogue: dense layers without row compaction only
+    if (w != 1 || a.rowmap || a.a_pitch || a.R || (a.N & 3) || (a.pool_w && !a.pool_part)) return hipErrorInvalidValue;
+    if (a.att_part) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 1>), dim3(nMt * nNt), dim3(256), smemw32, s, a, nMt, nNt, w);
+    else            hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 2>), dim3(nMt * nNt), dim3(256), smemw32, s, a, nMt, nNt, w);
+    return hipGetLastError();
+  }
   const bool tail = a.tail_mt > 0 && a.ksplit > 1 && a.partial && !a.a_pitch && !a.pool_part && !a.R && !a.raw &&
                     a.tail_mt < nMt && (a.N & 3) == 0;
   const int nMain = tail ? nMt - a.tail_mt : nMt;

@@ -303,6 +303,86 @@ hipError_t launch_att_pool(const float* value, int64_t ldv, int dv, const float*
   return hipGetLastError();
 }
 
+// ---- fused attentive pooling: the three small kernels around the attention epilogue of the GEMM (xv_epilogue.h)
+// scores[r, h] = scale * sum over the 32-channel blocks (ascending) of the partial dot products the key layer stored
+__global__ __launch_bounds__(256) void att_scores_reduce_kernel(const float* __restrict__ part, int64_t ld, int nblk, int H,
+                                                                int64_t rows, float scale, float* __restrict__ scores) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  for (int h = 0; h < H; ++h) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[((int64_t)b * H + h) * ld + r];     // coalesced across r
+    scores[r * H + h] = s * scale;
+  }
+}
+
+hipError_t launch_att_scores_reduce(const float* part, int64_t ld, int nblk, int H, int64_t rows, float scale,
+                                    float* scores, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(att_scores_reduce_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, ld, nblk, H, rows,
+                     scale, scores);
+  return hipGetLastError();
+}
+
+// s0[slot * H + h]: sum of the (normalised) weights of utterance b inside each 64-row tile; one thread per slot and head
+__global__ __launch_bounds__(64) void att_slot_sums_kernel(const float* __restrict__ w, int H, const int32_t* __restrict__ off0,
+                                                           int ctx, const int32_t* __restrict__ slotbase, float* __restrict__ s0) {
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int r0 = off0[b] - b * ctx, r1 = off0[b + 1] - (b + 1) * ctx;
+  const int t0 = r0 >> 6, t1 = (r1 - 1) >> 6;
+  for (int t = t0 + (int)threadIdx.x; t <= t1; t += 64) {
+    const int a = max(r0, t << 6), e = min(r1, (t + 1) << 6);
+    float s = 0.f;
+    for (int r = a; r < e; ++r) s += w[(int64_t)r * H + h];
+    s0[((int64_t)slotbase[b] + t) * H + h] = s;
+  }
+}
+
+hipError_t launch_att_slot_sums(const float* weights, int H, const int32_t* off0, int B, int ctx, const int32_t* slotbase,
+                                float* s0, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(att_slot_sums_kernel, dim3(B, H), dim3(64), 0, s, weights, H, off0, ctx, slotbase, s0);
+  return hipGetLastError();
+}
+
+// Weighted Chan merge of the per-slot moments of one utterance, in slot order (deterministic):
+//   mean = sum_s s1_s            (the weights of an utterance sum to 1: model/pooling.py:197,203)
+//   var  = sum_s [ m2_s + s0_s (s1_s / s0_s - mean)^2 ]      (= sum_t w_t (x_t - mean)^2, :204-206)
+// grid (ceil(odim / 256), B); column oc belongs to head oc / dvh (split value) or oc / (odim / H).
+__global__ __launch_bounds__(256) void att_pool_finalize_kernel(const float* __restrict__ part, const float* __restrict__ s0,
+                                                                int odim, int H, int dvh, int split,
+                                                                const int32_t* __restrict__ off0, int ctx,
+                                                                const int32_t* __restrict__ slotbase, float* __restrict__ out,
+                                                                int64_t ldo) {
+  const int b = blockIdx.y;
+  const int oc = blockIdx.x * 256 + threadIdx.x;
+  if (oc >= odim) return;
+  const int h = min(split ? oc / dvh : oc / (odim / H), H - 1);
+  const int r0 = off0[b] - b * ctx, r1 = off0[b + 1] - (b + 1) * ctx;
+  const int t0 = r0 >> 6, t1 = (r1 - 1) >> 6;
+  const int64_t base = (int64_t)slotbase[b];
+  float mean = 0.f;
+  for (int t = t0; t <= t1; ++t) mean += part[((base + t) * 2) * odim + oc];
+  float var = 0.f;
+  for (int t = t0; t <= t1; ++t) {
+    const float w = s0[(base + t) * H + h];
+    const float d = w > 0.f ? part[((base + t) * 2) * odim + oc] / w - mean : 0.f;
+    var += part[((base + t) * 2 + 1) * odim + oc] + w * d * d;
+  }
+  var = var <= kVarFloor ? kVarFloor : var;                     // model/pooling.py:215-216
+  out[(int64_t)b * ldo + oc] = mean;
+  out[(int64_t)b * ldo + odim + oc] = sqrtf(var);
+}
+
+hipError_t launch_att_pool_finalize(const float* part, const float* s0, int odim, int H, int dvh, int split,
+                                    const int32_t* off0, int B, int ctx, const int32_t* slotbase, float* out, int64_t ldo,
+                                    hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(att_pool_finalize_kernel, dim3((odim + 255) / 256, B), dim3(256), 0, s, part, s0, odim, H, dvh, split,
+                     off0, ctx, slotbase, out, ldo);
+  return hipGetLastError();
+}
+
 // endpoints["attention_weights"] [b,h,l] for a uniform-length batch (model/pooling.py:198)
 __global__ void att_weights_out_kernel(const float* __restrict__ scores, int H,
                                        const int32_t* __restrict__ off0, int ctx, float* __restrict__ out) {

@@ -494,6 +494,146 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
   }
 }
 
+// Attention epilogue of the 128-frame x 32-channel wave tile (kernel instantiations with EPI = 1; dense layers only:
+// no rowmap).  Two forms, see GemmArgs:
+//  * att_part: the tile is the last key layer's output and only its dot products with the query are wanted
+//    (model/pooling.py:189-194).  A lane holds 16 channels of one frame per MFMA tile, so the partial score of
+//    (frame, head) is 16 FMAs in-lane plus one exchange between the two lane halves; the 32 frames of an MFMA tile
+//    are stored as one 128-byte run.  The 1500-wide key never leaves the registers.
+//  * pool_w: the tile is the value and only its weighted moments are wanted (:201-217): 64 frames are staged in the
+//    wave-private LDS scratch as in the statistics form, then per utterance segment and head s1 = sum w x and
+//    m2 = sum w (x - s1 / s0)^2 go to the segment's slot.
+template <int ACT, int FORM>
+__device__ __forceinline__ void store_wave_tile_n32_att_impl(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
+                                                             int lane, int wave, char* lds) {
+  const int r32 = lane & 31, h = lane >> 5;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sc[4], sh[4], al[4];                            // this lane's channels 8q + 4h .. +3, q = 0..3
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n4 = nbase + 8 * q + 4 * h;
+    const bool ok = n4 < p.N;
+    sc[q] = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
+    sh[q] = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
+    al[q] = (ok && p.alpha) ? *reinterpret_cast<const f32x4*>(p.alpha + n4) : z;
+  }
+  auto value4 = [&](const f32x16& t, int q) -> f32x4 {
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = apply_act(fmaf(t[4 * q + i], sc[q][i], sh[q][i]), ACT < 0 ? p.act : ACT, al[q][i]);
+    return v;
+  };
+  if constexpr (FORM == 1) {
+    const int blk = nbase >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      f32x4 v[4];                                        // this lane's 16 channels of frame mi * 32 + r32, activated
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = value4(acc[mi], q);   // padding channels: scale = shift = 0 and query 0
+      const int m = mbase + mi * 32 + r32;
+      for (int hd = 0; hd < p.att_heads; ++hd) {
+        const float* qp = p.att_q + (int64_t)hd * p.Npad + nbase + 4 * h;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + 8 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s = fmaf(v[q][i], qv[i], s);
+        }
+        s += __shfl_xor(s, 32, 64);                      // the other 16 channels of this frame
+        if (h == 0 && m < p.M) p.att_part[((int64_t)blk * p.att_heads + hd) * p.att_ld + m] = s;
+      }
+    }
+    return;
+  } else {
+  // ---- weighted moments of the value
+  char* scratch = lds + wave * (64 * 128);
+  const int rrow = lane >> 3, rchunk = lane & 7;        // read-back map: 8 frames x 8 chunks per pass
+  const int n = nbase + rchunk * 4;
+  const bool nok = n < p.N;
+  const int H = p.pool_heads;
+  const int hd0 = p.pool_split ? min(nbase / p.pool_dvh, H - 1) : 0;     // split value: one head per 32-channel block
+  const int hd1 = p.pool_split ? hd0 + 1 : H;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+    for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = ml * 32 + r32;
+        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((2 * q + h) ^ (row & 7)) << 4)) = value4(acc[ps * 2 + ml], q);
+      }
+    wave_lds_sync();
+    const int mb = mbase + ps * 64;
+    const int my_utt = (mb + lane < p.M) ? p.pool_row2utt[mb + lane] : -1;
+    const int tile64 = mb >> 6;
+    auto row4 = [&](int t) -> f32x4 {
+      return *reinterpret_cast<const f32x4*>(scratch + t * 128 + ((rchunk ^ (t & 7)) << 4));
+    };
+    auto groups_sum = [&](f32x4 v) -> f32x4 {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] += __shfl_xor(v[i], 8, 64);
+        v[i] += __shfl_xor(v[i], 16, 64);
+        v[i] += __shfl_xor(v[i], 32, 64);
+      }
+      return v;
+    };
+    for (int hd = hd0; hd < hd1; ++hd) {
+      const float wl = (mb + lane < p.M) ? p.pool_w[(int64_t)(mb + lane) * H + hd] : 0.f;   // lane = frame of this pass
+      const int oc = p.pool_split ? n : hd * p.N + n;
+      int r = 0;
+      while (r < 64) {
+        const int b = __builtin_amdgcn_readlane(my_utt, r);
+        int re = r + 1;
+        while (re < 64 && __builtin_amdgcn_readlane(my_utt, re) == b) ++re;
+        if (b >= 0) {
+          float s0 = (lane >= r && lane < re) ? wl : 0.f;           // sum of the segment's weights
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) s0 += __shfl_xor(s0, o, 64);
+          f32x4 s1 = z;
+          for (int t0 = r & ~7; t0 < re; t0 += 8) {
+            const int t = t0 + rrow;
+            const float wt = __shfl(wl, t & 63, 64);
+            if (t >= r && t < re) s1 += row4(t) * wt;
+          }
+          s1 = groups_sum(s1);
+          const float inv = s0 > 0.f ? 1.0f / s0 : 0.f;
+          const f32x4 mu = s1 * inv;
+          f32x4 m2 = z;
+          for (int t0 = r & ~7; t0 < re; t0 += 8) {
+            const int t = t0 + rrow;
+            const float wt = __shfl(wl, t & 63, 64);
+            if (t >= r && t < re) {
+              const f32x4 d = row4(t) - mu;
+              m2 += d * d * wt;
+            }
+          }
+          m2 = groups_sum(m2);
+          if (nok && rrow == 0) {
+            const int64_t slot = (int64_t)p.pool_slotbase[b] + tile64;
+            *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2) * p.pool_odim + oc) = s1;
+            *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2 + 1) * p.pool_odim + oc) = m2;
+          }
+        }
+        r = re;
+      }
+    }
+    wave_lds_sync();
+  }
+  }
+}
+
+// FORM 1 = score partials (GemmArgs::att_part), 2 = weighted moments (GemmArgs::pool_w)
+template <int FORM>
+__device__ __forceinline__ void store_wave_tile_n32_att(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
+                                                        int lane, int wave, char* lds) {
+  if (p.act == ACT_RELU)
+    store_wave_tile_n32_att_impl<ACT_RELU, FORM>(p, acc, mbase, nbase, lane, wave, lds);
+  else
+    store_wave_tile_n32_att_impl<-1, FORM>(p, acc, mbase, nbase, lane, wave, lds);
+}
+
 // Epilogue entry for the 128x32 wave tile.
 template <int ROWS>
 __device__ __forceinline__ void store_wave_tile_n32(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,

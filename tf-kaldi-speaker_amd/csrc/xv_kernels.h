@@ -70,6 +70,25 @@ struct GemmArgs {
   // residual shortcut added before the activation (resnet.py:84-85,147-148): fp32 [rows, N]
   const float* R;
   int64_t ldr;
+  // ---- fused attentive pooling (model/pooling.py:189-217), bf16x3 kernel with the attention epilogue (EPI = 1):
+  // (a) last key layer: instead of storing the key, every wave stores the partial scores of its 32 channels,
+  //       att_part[((n / 32) * att_heads + h) * att_ld + m] = sum_{n' in block} act(...)[m, n'] * att_q[h * Npad + n']
+  //     (att_q = the query expanded per head over the padded key width, zero outside the head's slice; the scale of
+  //     :193-194 and the ordered sum over the blocks are applied by launch_att_scores_reduce);
+  const float* att_q = nullptr;
+  float* att_part = nullptr;
+  int64_t att_ld = 0;
+  int att_heads = 0;
+  // (b) value layer: instead of storing the value, per 64-frame tile and utterance segment the weighted moments
+  //       pool_part[(slot * 2 + 0) * pool_odim + oc] = sum_t w[t, h] x[t, c]
+  //       pool_part[(slot * 2 + 1) * pool_odim + oc] = sum_t w[t, h] (x[t, c] - s1 / s0)^2,   s0 = sum_t w[t, h]
+  //     with pool_w = the softmax output [rows, pool_heads]; split value (:151-157): h = c / pool_dvh, oc = c; else
+  //     every head pools every channel, oc = h * N + c.  launch_att_pool_finalize merges the slots (weighted Chan).
+  const float* pool_w = nullptr;
+  int pool_heads = 0;
+  int pool_split = 0;
+  int pool_dvh = 0;
+  int pool_odim = 0;
 };
 
 // fp32 MFMA (v_mfma_f32_32x32x2_f32) path.  aligned: ldx == cin (or K == cin), ldx % 4 == 0,
@@ -147,6 +166,19 @@ hipError_t launch_att_scores(const float* key, int64_t ldk, int64_t rows, const 
 // softmax over time per (utterance, head), in place on scores [rows, H]; also writes the
 // [B, H, Lmax]-free packed layout weights_out[h * rows + r] when weights_out != nullptr.
 hipError_t launch_att_softmax(float* scores, int H, const int32_t* off0, int B, int ctx, hipStream_t s);
+// fused attention (csrc/xv_epilogue.h, attention epilogue of the bf16x3 GEMM):
+// scores[r, h] = scale * sum_blk part[(blk * H + h) * ld + r], blocks in ascending order (deterministic)
+hipError_t launch_att_scores_reduce(const float* part, int64_t ld, int nblk, int H, int64_t rows, float scale,
+                                    float* scores, hipStream_t s);
+// per-slot weight sums for the weighted Chan merge: s0[slot * H + h] = sum of weights[r, h] over the rows of utterance b
+// inside 64-row tile t, slot = slotbase[b] + t (rows in ascending order)
+hipError_t launch_att_slot_sums(const float* weights, int H, const int32_t* off0, int B, int ctx, const int32_t* slotbase,
+                                float* s0, hipStream_t s);
+// out[b] = [sum_s s1 ..., sqrt(max-floor(sum_s m2_s + s0_s (s1_s / s0_s - mean)^2)) ...] over the slots of utterance b
+hipError_t launch_att_pool_finalize(const float* part, const float* s0, int odim, int H, int dvh, int split,
+                                    const int32_t* off0, int B, int ctx, const int32_t* slotbase, float* out, int64_t ldo,
+                                    hipStream_t s);
+
 // weighted mean / std (model/pooling.py:201-218).  value [rows, dv]; out[b] = [mean(h,d)..., std(h,d)...]
 hipError_t launch_att_pool(const float* value, int64_t ldv, int dv, const float* weights, int H,
                            int split_value, const int32_t* off0, int B, int ctx, float* out, int64_t ldo,

@@ -139,6 +139,8 @@ struct xv_handle {
   // options (xv_set_option)
   int opt_pool_fusion = 1;                            // statistics pooling fused into the last frame layer's epilogue
   int opt_tail_split = 1;                             // K-split of the last, nearly empty round of GEMM tiles
+  int opt_att_fusion = 1;                             // attention scores / weighted moments in the GEMM epilogues
+  int opt_profile_dominant = 0;                       // xv_profile_*: bracket only the step with the most FLOPs of a plan
   // device index arrays of destroyed plans, kept for the next plan (no hipMalloc / hipFree per ragged batch)
   std::mutex pool_mu;
   std::vector<DevBuf> pool;
@@ -150,6 +152,9 @@ struct xv_handle {
   std::vector<Node> nodes;
   // attention extras
   DevBuf query;                 // [H, dk_h]
+  DevBuf query_eff;             // [H, Npad of the last key layer]: the query of head h over the padded key width, zero
+                                // outside the head's slice (fused score epilogue)
+  int key_npad = 0;
   int att_dk_h = 0, att_dk = 0, att_dv = 0;
   int final_ctx = 14;           // temporal context of the pooled frames (tdnn 14, etdnn 22)
   std::string post_bn_scope, post_alpha_name;
@@ -179,6 +184,11 @@ struct PlanStep {
   int ksplit = 1;               // split-K slices of a small-M fp32 GEMM, or of the tail M tiles of a bf16x3 GEMM
   int tail_mt = 0;              // bf16x3: M tiles computed K-split (gemm_bf16x3_tail_plan)
   bool fuse_pool = false;       // GEMM: emit pooling partials instead of activations; STAT_POOL: finalize only
+  int fuse_att = 0;             // GEMM: 1 = score partials instead of the key, 2 = weighted moments instead of the value;
+                                // ATT_SCORES / ATT_SOFTMAX / ATT_POOL: 1 = the fused form of that op
+  int64_t att_w_off = -1;       // fuse_att 2: workspace offset of the softmax output (weights [rows, H])
+  int64_t att_s0_off = -1;      // workspace offset of the per-slot weight sums [pool_slots, H]
+  int64_t att_ld = 0;           // fuse_att 1: row stride of the partial-score planes
   bool unpad_to_out = false;    // grid-valued target node: GEMM writes the padded grid, then it is unpadded into `out`
   int64_t flops = 0, bytes = 0;
 };
@@ -197,6 +207,7 @@ struct xv_plan {
   int64_t pool_slots = 0;
   bool uniform_len = true;
   int uniform_L = 0;
+  int dominant_step = 0;            // index of the step with the most algorithmic FLOPs
 };
 
 namespace {
@@ -753,6 +764,18 @@ int xv_finalize(xv_handle* h) {
     const auto& q = T(h, std::string(h->desc.network_type == XV_NET_ETDNN ? "etdnn/" : "tdnn/") + "attention/query").data;
     XV_HIP(h, h->query.alloc(q.size() * sizeof(float)));
     XV_HIP(h, hipMemcpy(h->query.p, q.data(), q.size() * sizeof(float), hipMemcpyHostToDevice));
+    {
+      const int H = h->desc.att_num_heads, dkh = h->att_dk_h;
+      h->key_npad = (int)align_up(h->att_dk, 128);
+      std::vector<float> qe((size_t)H * h->key_npad, 0.f);
+      for (int hd = 0; hd < H; ++hd)
+        for (int d = 0; d < dkh; ++d) {
+          const int n = h->desc.att_split_key ? hd * dkh + d : d;
+          qe[(size_t)hd * h->key_npad + n] = q[(size_t)hd * dkh + d];
+        }
+      XV_HIP(h, h->query_eff.alloc(qe.size() * sizeof(float)));
+      XV_HIP(h, hipMemcpy(h->query_eff.p, qe.data(), qe.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (h->desc.att_apply_nonlinear) {
       const int n = h->pool_dim;
       std::vector<double> s, t;
@@ -778,6 +801,8 @@ int xv_set_option(xv_handle* h, const char* name, int value) {
   std::lock_guard<std::mutex> lk(h->mu);
   if (!strcmp(name, "pool_fusion")) h->opt_pool_fusion = value != 0;
   else if (!strcmp(name, "tail_split")) h->opt_tail_split = value != 0;
+  else if (!strcmp(name, "att_fusion")) h->opt_att_fusion = value != 0;
+  else if (!strcmp(name, "profile_dominant")) h->opt_profile_dominant = value != 0;
   else return fail(h, XV_ERR_INVALID, "xv_set_option: unknown option '%s'", name);
   return XV_OK;
 }
@@ -838,9 +863,47 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
   p->uniform_len = uniform;
   p->uniform_L = frame_offsets[1] - frame_offsets[0];
 
-  // liveness: last step index that reads each value
   std::vector<int> order;
   for (size_t i = 0; i < h->ops.size(); ++i) if (need[i]) order.push_back((int)i);
+
+  // Fused attentive pooling (bf16x3 kernel, attention epilogue): the last key layer emits score partials instead of
+  // the key when the scores are its only reader; the value layer emits weighted moments instead of the value when
+  // the pooling is its only reader -- it then has to run AFTER the softmax, so it is moved behind it in the order.
+  auto readers_of = [&](int v) {
+    int n = 0;
+    for (int o2 : order)
+      if (h->ops[o2].in0 == v || h->ops[o2].in1 == v) ++n;
+    return n;
+  };
+  int key_prod = -1, val_prod = -1, att_pool_value = -1;
+  if (h->opt_att_fusion && h->desc.pooling_type == XV_POOL_SELF_ATTENTION && h->desc.att_num_heads <= 8) {
+    auto fusable = [&](int v) {
+      if (v <= 0 || producer[v] < 0 || producer[v] == node.op) return -1;
+      const Op& prod = h->ops[producer[v]];
+      if (prod.kind != OP_GEMM || prod.in1 > 0 || readers_of(v) != 1) return -1;
+      const Layer& L = h->layers[prod.layer];
+      return (L.use_split && !L.im2col && L.mode == 0 && L.w == 1 && (L.cout & 3) == 0) ? producer[v] : -1;
+    };
+    int softmax_op = -1, pool_op = -1;
+    for (int o : order) {
+      if (h->ops[o].kind == OP_ATT_SCORES) key_prod = fusable(h->ops[o].in0);
+      if (h->ops[o].kind == OP_ATT_SOFTMAX) softmax_op = o;
+      if (h->ops[o].kind == OP_ATT_POOL) pool_op = o;
+    }
+    if (pool_op >= 0 && softmax_op >= 0) {
+      const int H = h->desc.att_num_heads, dv = h->att_dv;
+      const bool heads_ok = H == 1 || !h->desc.att_split_value || (dv / H) % 32 == 0;
+      const int vp = heads_ok ? fusable(h->ops[pool_op].in0) : -1;
+      if (vp >= 0) {
+        val_prod = vp;
+        att_pool_value = h->ops[pool_op].in0;
+        order.erase(std::find(order.begin(), order.end(), vp));
+        order.insert(std::find(order.begin(), order.end(), pool_op), vp);
+      }
+    }
+  }
+
+  // liveness: last step index that reads each value
   std::vector<int> last_use(h->values.size(), -1);
   for (size_t s = 0; s < order.size(); ++s)
     for (int in : {h->ops[order[s]].in0, h->ops[order[s]].in1})
@@ -901,8 +964,9 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       if (h->ops[o2].in0 == op.in0 || h->ops[o2].in1 == op.in0) ++readers;
     if (readers == 1 && L.w == 1 && (L.cout & 3) == 0 && h->opt_pool_fusion) fused_value = op.in0;
   }
-  if (fused_value >= 0) {
-    const int ctx = h->values[fused_value].ctx;
+  const int slot_value = fused_value >= 0 ? fused_value : att_pool_value;   // the value whose rows are pooled per 64-row slot
+  if (slot_value >= 0) {
+    const int ctx = h->values[slot_value].ctx;
     std::vector<int32_t> slotbase(batch);
     int64_t nslots = 0;
     for (int b = 0; b < batch; ++b) {
@@ -952,7 +1016,8 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       } else if (!L.use_split && op.out != fused_value) {
         st.ksplit = gemm_f32_ksplit(st.M, L.Kpad, L.Npad);
         if (st.ksplit > 1) scratch = (int64_t)st.ksplit * st.M * L.Npad * 4;
-      } else if (L.use_split && L.mode == 0 && op.out != fused_value && op.in1 <= 0 && h->opt_tail_split) {
+      } else if (L.use_split && L.mode == 0 && op.out != fused_value && op.in1 <= 0 && h->opt_tail_split &&
+                 order[s] != key_prod && order[s] != val_prod) {
         scratch = gemm_bf16x3_tail_plan(st.M, L.Kpad, L.Npad, L.w, &st.tail_mt, &st.ksplit);
       }
       if (scratch > 0) {
@@ -962,6 +1027,10 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     } else if (op.kind == OP_AFFINE_ACT) {
       st.stage = st.to_out ? node.stage : 2;
       st.bytes = 8 * st.rows_out * h->values[op.out].cols;
+    } else if (op.kind == OP_ATT_POOL && val_prod >= 0) {      // finalize only: reads the weighted (s1, m2) slots
+      st.fuse_att = 1;
+      st.bytes = 4 * (p->pool_slots * (2 * (h->pool_dim / 2) + h->desc.att_num_heads) + st.rows_out * h->values[op.out].cols);
+      st.flops = 8 * p->pool_slots * (h->pool_dim / 2);
     } else if (op.kind == OP_STAT_POOL || op.kind == OP_ATT_POOL) {
       st.bytes = 4 * (st.rows_in * h->values[op.in0].cols + st.rows_out * h->values[op.out].cols);
       st.flops = 4 * st.rows_in * h->values[op.in0].cols;
@@ -973,6 +1042,11 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     } else if (op.kind == OP_ATT_SCORES) {
       st.bytes = 4 * st.rows_in * h->values[op.in0].cols;
       st.flops = 2 * st.rows_in * (int64_t)h->att_dk_h * h->desc.att_num_heads;
+      if (key_prod >= 0) {               // reduce form: reads the partial planes
+        st.fuse_att = 1;
+        st.att_ld = align_up(st.rows_in, 64);
+        st.bytes = 4 * (st.att_ld * (h->key_npad / 32) + st.rows_in) * h->desc.att_num_heads;
+      }
     } else {
       st.bytes = 8 * st.rows_out * h->values[op.out].cols;
     }
@@ -983,6 +1057,10 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       vsize[op.out] = vsize[op.in0];
       vsize[op.in0] = 0;                 // ownership moves to the softmax value
       st.out_off = voff[op.out];
+      if (val_prod >= 0) {               // the per-slot weight sums live behind the weights (block sized by ATT_SCORES)
+        st.fuse_att = 1;
+        st.att_s0_off = voff[op.out] + align_up(st.rows_out * (int64_t)h->desc.att_num_heads * 4, kAlign);
+      }
     } else if (st.to_out && !node.att_weights && h->values[op.out].grid_F == 0) {
       st.out_off = -1;                   // straight into the caller's output buffer (fp32)
     } else if (st.to_out && !node.att_weights) {
@@ -991,13 +1069,33 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       voff[op.out] = arena_alloc(vsize[op.out]);
       st.out_off = voff[op.out];
     } else {
-      if (op.out == fused_value) {
+      if (op.kind == OP_GEMM && order[s] == key_prod) {
+        st.fuse_att = 1;                    // [Npad / 32][H] planes of partial scores, row stride att_ld
+        st.att_ld = align_up(st.rows_out, 64);
+        vsize[op.out] = align_up((int64_t)(h->layers[op.layer].Npad / 32) * h->desc.att_num_heads * st.att_ld * 4, kAlign);
+        voff[op.out] = arena_alloc(vsize[op.out]);
+        st.out_off = voff[op.out];
+        st.bytes = 4 * (st.rows_in * h->layers[op.layer].cin + (int64_t)h->layers[op.layer].K() * h->layers[op.layer].cout) +
+                   vsize[op.out];
+      } else if (op.kind == OP_GEMM && order[s] == val_prod) {
+        st.fuse_att = 2;                    // weighted (s1, m2) per slot and output column
+        vsize[op.out] = align_up(p->pool_slots * 2 * (int64_t)(h->pool_dim / 2) * 4, kAlign);
+        voff[op.out] = arena_alloc(vsize[op.out]);
+        st.out_off = voff[op.out];
+        st.bytes = 4 * (st.rows_in * h->layers[op.layer].cin + (int64_t)h->layers[op.layer].K() * h->layers[op.layer].cout +
+                        st.rows_out * h->desc.att_num_heads) + vsize[op.out];
+        for (const PlanStep& prev : p->steps)
+          if (h->ops[prev.op].kind == OP_ATT_SOFTMAX) { st.att_w_off = prev.out_off; st.att_s0_off = prev.att_s0_off; }
+      } else if (op.out == fused_value) {
         st.fuse_pool = true;
         vsize[op.out] = align_up(p->pool_slots * 2 * (int64_t)h->values[op.out].cols * 4, kAlign);
         voff[op.out] = arena_alloc(vsize[op.out]);
         st.out_off = voff[op.out];
       } else if (want_f32[op.out] || node.att_weights) {
         vsize[op.out] = value_bytes(h, op.out, F0, batch);
+        if (op.kind == OP_ATT_SCORES && val_prod >= 0)       // + the per-slot weight sums written by the softmax step
+          vsize[op.out] = align_up(st.rows_out * (int64_t)h->desc.att_num_heads * 4, kAlign) +
+                          align_up(p->pool_slots * (int64_t)h->desc.att_num_heads * 4, kAlign) + kAlign;
         voff[op.out] = arena_alloc(vsize[op.out]);
         st.out_off = voff[op.out];
       }
@@ -1007,6 +1105,9 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
         st.out_sb_off = voff_sb[op.out];
       }
     }
+    if (op.kind == OP_ATT_POOL && val_prod >= 0)
+      for (const PlanStep& prev : p->steps)
+        if (h->ops[prev.op].kind == OP_ATT_SOFTMAX) st.att_s0_off = prev.att_s0_off;
     p->steps.push_back(st);
     if (step_scratch > 0) arena_free(st.scratch_off, step_scratch);
     for (int in : {op.in0, op.in1})
@@ -1015,6 +1116,9 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
         if (vsize_sb[in] > 0) { arena_free(voff_sb[in], vsize_sb[in]); vsize_sb[in] = 0; }
       }
   }
+
+  for (size_t i = 0; i < p->steps.size(); ++i)
+    if (p->steps[i].flops > p->steps[p->dominant_step].flops) p->dominant_step = (int)i;
 
   // output shape
   const Op& top = h->ops[node.op];
@@ -1072,9 +1176,9 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       if (e != hipSuccess) return bail(e, "build_rowmap");
     }
   }
-  if (fused_value >= 0) {
-    const int ctx = h->values[fused_value].ctx;
-    const int64_t rows = value_rows(h, fused_value, F0, batch);
+  if (slot_value >= 0) {
+    const int ctx = h->values[slot_value].ctx;
+    const int64_t rows = value_rows(h, slot_value, F0, batch);
     if ((e = pool_take(h, (size_t)rows * 4, p->d_row2utt)) != hipSuccess) return bail(e, "hipMalloc(row2utt)");
     if ((e = pool_take(h, (size_t)batch * 4, p->d_slotbase)) != hipSuccess) return bail(e, "hipMalloc(slotbase)");
     if ((e = hipMemcpyAsync(p->d_slotbase.p, p->offsets_slotbase.data(), (size_t)batch * 4, hipMemcpyHostToDevice, s)) != hipSuccess)
@@ -1168,7 +1272,8 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
     float* optr = st.out_off >= 0 ? reinterpret_cast<float*>(ws + st.out_off) : out;
     (void)split;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
-    if (prof) {
+    const bool prof_step = prof && (!h->opt_profile_dominant || (int)si == p->dominant_step);
+    if (prof_step) {
       pe0 = h->prof_pool[prof_base + 2 * si];
       pe1 = h->prof_pool[prof_base + 2 * si + 1];
       XV_HIP(h, hipEventRecord(pe0, s));
@@ -1204,6 +1309,23 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           a.cin = a.K;                      // one "frame" per A row for the kernel's tap logic (w = 1)
         }
         if (op.in1 > 0) { a.R = in_ptr(st.in1_off); a.ldr = L.cout; }
+        if (st.fuse_att == 1) {             // partial scores instead of the key (model/pooling.py:189-194)
+          a.Y = nullptr;
+          a.att_part = reinterpret_cast<float*>(ws + st.out_off);
+          a.att_ld = st.att_ld;
+          a.att_heads = d.att_num_heads;
+          a.att_q = static_cast<const float*>(h->query_eff.p);
+        } else if (st.fuse_att == 2) {      // weighted moments instead of the value (:201-217)
+          a.Y = nullptr;
+          a.pool_part = reinterpret_cast<float*>(ws + st.out_off);
+          a.pool_row2utt = static_cast<const int32_t*>(p->d_row2utt.p);
+          a.pool_slotbase = static_cast<const int32_t*>(p->d_slotbase.p);
+          a.pool_w = reinterpret_cast<const float*>(ws + st.att_w_off);
+          a.pool_heads = d.att_num_heads;
+          a.pool_split = d.att_split_value;
+          a.pool_dvh = d.att_split_value ? L.cout / d.att_num_heads : L.cout;
+          a.pool_odim = h->pool_dim / 2;
+        }
         if (st.fuse_pool) {                 // statistics pooling partials instead of activations
           a.Y = nullptr;
           a.pool_part = reinterpret_cast<float*>(ws + st.out_off);
@@ -1286,6 +1408,11 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
       case OP_ATT_SCORES: {
         const Value& vi = h->values[op.in0];
         const float scale = d.att_use_scale ? 1.0f / std::sqrt((float)h->att_dk_h) : 1.0f;   // model/pooling.py:193-194
+        if (st.fuse_att) {
+          XV_HIP(h, launch_att_scores_reduce(in_ptr(st.in0_off), st.att_ld, h->key_npad / 32, d.att_num_heads, st.rows_in,
+                                             scale, reinterpret_cast<float*>(ws + st.out_off), s));
+          break;
+        }
         XV_HIP(h, launch_att_scores(in_ptr(st.in0_off), vi.cols, st.rows_in, static_cast<const float*>(h->query.p),
                                     d.att_num_heads, h->att_dk_h, d.att_split_key, scale,
                                     reinterpret_cast<float*>(ws + st.out_off), s));
@@ -1294,11 +1421,21 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
       case OP_ATT_SOFTMAX: {
         float* sc = reinterpret_cast<float*>(ws + st.out_off);
         XV_HIP(h, launch_att_softmax(sc, d.att_num_heads, off, B, h->final_ctx, s));
+        if (st.fuse_att)
+          XV_HIP(h, launch_att_slot_sums(sc, d.att_num_heads, off, B, h->final_ctx, static_cast<const int32_t*>(p->d_slotbase.p),
+                                         reinterpret_cast<float*>(ws + st.att_s0_off), s));
         if (st.to_out) XV_HIP(h, launch_att_weights_out(sc, d.att_num_heads, off, B, h->final_ctx, out, s));
         break;
       }
       case OP_ATT_POOL: {
         const Value& vv = h->values[op.in0];
+        if (st.fuse_att) {
+          XV_HIP(h, launch_att_pool_finalize(in_ptr(st.in0_off), reinterpret_cast<const float*>(ws + st.att_s0_off),
+                                             h->pool_dim / 2, d.att_num_heads, d.att_split_value ? vv.cols / d.att_num_heads : vv.cols,
+                                             d.att_split_value, off, B, vv.ctx, static_cast<const int32_t*>(p->d_slotbase.p),
+                                             optr, h->pool_dim, s));
+          break;
+        }
         XV_HIP(h, launch_att_pool(in_ptr(st.in0_off), vv.cols, vv.cols, in_ptr(st.in1_off), d.att_num_heads,
                                   d.att_split_value, off, B, vv.ctx, optr, h->pool_dim, s));
         break;
@@ -1318,7 +1455,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
       default:
         return fail(h, XV_ERR_STATE, "unknown op kind %d", op.kind);
     }
-    if (prof) {
+    if (prof_step) {
       XV_HIP(h, hipEventRecord(pe1, s));
       std::lock_guard<std::mutex> lk(h->prof_mu);
       h->prof_recs.push_back({pe0, pe1, p, (int)si});
@@ -1433,6 +1570,7 @@ void xv_destroy(xv_handle* h) {
     DeviceGuard g(h->device);
     for (auto& L : h->layers) { L.wt.release(); L.wsb.release(); L.wfr.release(); L.vec.release(); }
     h->query.release();
+    h->query_eff.release();
     h->post_vec.release();
     for (auto& b : h->pool) b.release();
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);

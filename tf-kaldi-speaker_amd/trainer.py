@@ -215,6 +215,8 @@ class Trainer(object):
         self._options[name] = int(value)
         if self._h is not None:
             _lib.check(self._lib.xv_set_option(self._h, name.encode(), int(value)), self._h)
+            if name.startswith("profile"):
+                return                                   # does not change what a plan computes
             for k in [k for k in self._plans if k not in self._pinned_plans]:
                 self._lib.xv_plan_destroy(self._plans.pop(k)[0])
 
