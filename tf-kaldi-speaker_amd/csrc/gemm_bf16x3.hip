@@ -393,7 +393,7 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
 
   auto stamp = [&](int i) {
 #ifdef XV_GEMM_TRACE
-    if (p.trace && tid == 0) p.trace[(int64_t)blockIdx.x * 4 + i] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (p.trace && tid == 0) p.trace[(int64_t)blockIdx.x * 8 + i] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
   };
   stamp(0);
@@ -548,7 +548,7 @@ __global__ void bf16x3_tail_reduce_kernel(GemmArgs p, int mt0, int S) {
 
 #ifdef XV_GEMM_TRACE
 namespace {
-long long* g_trace = nullptr;      // debug trace buffer (device), kTraceWgs workgroups x 4 stamps
+long long* g_trace = nullptr;      // debug trace buffer (device), kTraceWgs workgroups x 8 stamps (0-3: kernel phases, 4-7: inside the epilogue)
 int g_trace_wgs = 0;
 constexpr int kTraceWgs = 16384;
 }  // namespace
@@ -577,12 +577,21 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
 #ifdef XV_GEMM_TRACE
   {
-    static int trace_k = -1;
-    if (trace_k < 0) { const char* e = getenv("XVEC_TRACE_K"); trace_k = e ? atoi(e) : 0; }
-    if (trace_k > 0 && a.K == trace_k) {
-      if (!g_trace && hipMalloc(&g_trace, sizeof(long long) * 4 * kTraceWgs) != hipSuccess) g_trace = nullptr;
+    static int trace_k = -1, trace_n = 0;
+    if (trace_k < 0) {
+      const char* e = getenv("XVEC_TRACE_K");
+      trace_k = e ? atoi(e) : 0;
+      const char* e2 = getenv("XVEC_TRACE_N");
+      trace_n = e2 ? atoi(e2) : 0;
+    }
+    if (trace_k > 0 && a.K == trace_k && (trace_n == 0 || a.N == trace_n)) {
+      if (!g_trace && hipMalloc(&g_trace, sizeof(long long) * 8 * kTraceWgs) != hipSuccess) g_trace = nullptr;
       const int wgs = ((a.M + BM - 1) / BM) * (a.Npad / BN);
-      if (g_trace && wgs <= kTraceWgs) { a.trace = g_trace; g_trace_wgs = wgs; }
+      if (g_trace && wgs <= kTraceWgs) {
+        a.trace = g_trace;
+        g_trace_wgs = wgs;
+        (void)hipMemsetAsync(g_trace, 0, sizeof(long long) * 8 * kTraceWgs, s);
+      }
     }
   }
 #endif
@@ -684,7 +693,7 @@ extern "C" int xvdbg_gemm_trace(long long* out, int max_wgs) {
   if (!xv::g_trace || xv::g_trace_wgs <= 0) return 0;
   const int n = xv::g_trace_wgs < max_wgs ? xv::g_trace_wgs : max_wgs;
   if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpy(out, xv::g_trace, sizeof(long long) * 4 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemcpy(out, xv::g_trace, sizeof(long long) * 8 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return n;
 }
 #endif

@@ -25,6 +25,18 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
   }
 }
 
+// debug (tools/gemm_trace.py, -DXV_GEMM_TRACE builds only): phase stamps 4..7 of the workgroup's first thread
+#ifdef XV_GEMM_TRACE
+#define XV_EPI_STAMP(p, i)                                                                                          \
+  do {                                                                                                              \
+    if ((p).trace && threadIdx.x == 0) (p).trace[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define XV_EPI_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define XV_EPI_STAMP(p, i) do {} while (0)
+#define XV_EPI_DRAIN() do {} while (0)
+#endif
+
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
@@ -334,6 +346,8 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       al[q] = (ok && p.alpha) ? *reinterpret_cast<const f32x4*>(p.alpha + n4) : z;
     }
   }
+  XV_EPI_DRAIN();                                        // (trace builds: make the parameter-load latency visible)
+  XV_EPI_STAMP(p, 4);
   auto value4 = [&](const f32x16& t, int q, bool pre_act) -> f32x4 {
     f32x4 v;
 #pragma unroll
@@ -408,6 +422,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
           *reinterpret_cast<uint2*>(rp + (((4 + q) ^ (row & 7)) << 4)) = make_uint2(l01, l23);
         }
       wave_lds_sync();
+      if (ps == 0) { XV_EPI_DRAIN(); XV_EPI_STAMP(p, 6); }
 #pragma unroll 4
       for (int it = 0; it < ROWS / 8; ++it) {
         const int row = it * 8 + rrow;
@@ -419,14 +434,17 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
           *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (nbase >> 5) * 128 +
                                     rchunk * 16) = v;
       }
+      if (ps == 0) XV_EPI_STAMP(p, 7);
       wave_lds_sync();
     }
   }
+  XV_EPI_STAMP(p, 5);
   if (p.Y || (ROWS == 64 && p.pool_part)) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       stage_f32(ps, false);
       wave_lds_sync();
+      if (ps == 0) XV_EPI_STAMP(p, 6);
       if (p.Y) {
 #pragma unroll 4
         for (int it = 0; it < ROWS / 8; ++it) {
@@ -458,37 +476,63 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
           }
           return v;
         };
-        int r = 0;
-        while (r < 64) {
-          const int b = __builtin_amdgcn_readlane(my_utt, r);
-          int re = r + 1;
-          while (re < 64 && __builtin_amdgcn_readlane(my_utt, re) == b) ++re;
-          if (b >= 0) {
-            f32x4 s1 = z;
-            for (int t0 = r & ~7; t0 < re; t0 += 8) {
-              const int t = t0 + rrow;
-              if (t >= r && t < re) s1 += row4(t);
-            }
-            s1 = groups_sum(s1);
-            const f32x4 mu = s1 / (float)(re - r);
-            f32x4 m2 = z;
-            for (int t0 = r & ~7; t0 < re; t0 += 8) {
-              const int t = t0 + rrow;
-              if (t >= r && t < re) {
-                const f32x4 d = row4(t) - mu;
-                m2 += d * d;
+        const int u_first = __builtin_amdgcn_readlane(my_utt, 0), u_last = __builtin_amdgcn_readlane(my_utt, 63);
+        if (u_first >= 0 && u_first == u_last) {
+          // the usual case: all 64 frames of the pass belong to one utterance (a 286-frame utterance has a boundary
+          // in one pass out of 4.5).  Fixed trip counts: the eight rows of a lane are read back to back.
+          f32x4 s1 = z;
+#pragma unroll 4
+          for (int k = 0; k < 8; ++k) s1 += row4(k * 8 + rrow);
+          s1 = groups_sum(s1);
+          const f32x4 mu = s1 * (1.0f / 64.0f);
+          f32x4 m2 = z;
+#pragma unroll 4
+          for (int k = 0; k < 8; ++k) {                 // second sweep of the LDS copy (registers are scarce here)
+            const f32x4 d = row4(k * 8 + rrow) - mu;
+            m2 += d * d;
+          }
+          m2 = groups_sum(m2);
+          if (nok && rrow == 0) {
+            const int64_t slot = (int64_t)p.pool_slotbase[u_first] + tile64;
+            *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2) * p.N + n) = s1;
+            *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2 + 1) * p.N + n) = m2;
+          }
+        } else {
+          // utterance boundaries (or the end of the matrix) inside the pass: one (sum, M2) pair per segment; the segment
+          // ends come from one ballot per segment instead of a lane-by-lane scan
+          int r = 0;
+          while (r < 64) {
+            const int b = __builtin_amdgcn_readlane(my_utt, r);
+            const unsigned long long same = __ballot(my_utt == b) >> r;          // bit 0 = lane r (set)
+            const int re = r + (~same ? __builtin_ctzll(~same) : 64 - r);
+            if (b >= 0) {
+              f32x4 s1 = z;
+              for (int t0 = r & ~7; t0 < re; t0 += 8) {
+                const int t = t0 + rrow;
+                if (t >= r && t < re) s1 += row4(t);
+              }
+              s1 = groups_sum(s1);
+              const f32x4 mu = s1 / (float)(re - r);
+              f32x4 m2 = z;
+              for (int t0 = r & ~7; t0 < re; t0 += 8) {
+                const int t = t0 + rrow;
+                if (t >= r && t < re) {
+                  const f32x4 d = row4(t) - mu;
+                  m2 += d * d;
+                }
+              }
+              m2 = groups_sum(m2);
+              if (nok && rrow == 0) {
+                const int64_t slot = (int64_t)p.pool_slotbase[b] + tile64;
+                *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2) * p.N + n) = s1;
+                *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2 + 1) * p.N + n) = m2;
               }
             }
-            m2 = groups_sum(m2);
-            if (nok && rrow == 0) {
-              const int64_t slot = (int64_t)p.pool_slotbase[b] + tile64;
-              *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2) * p.N + n) = s1;
-              *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2 + 1) * p.N + n) = m2;
-            }
+            r = re;
           }
-          r = re;
         }
       }
+      if (ps == 0) XV_EPI_STAMP(p, 7);
       wave_lds_sync();
     }
   }
@@ -508,19 +552,20 @@ __device__ __forceinline__ void store_wave_tile_n32_att_impl(const GemmArgs& p, 
                                                              int lane, int wave, char* lds) {
   const int r32 = lane & 31, h = lane >> 5;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  f32x4 sc[4], sh[4], al[4];                            // this lane's channels 8q + 4h .. +3, q = 0..3
+  f32x4 sc[4], sh[4];                                   // this lane's channels 8q + 4h .. +3, q = 0..3
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int n4 = nbase + 8 * q + 4 * h;
     const bool ok = n4 < p.N;
     sc[q] = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
     sh[q] = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
-    al[q] = (ok && p.alpha) ? *reinterpret_cast<const f32x4*>(p.alpha + n4) : z;
   }
   auto value4 = [&](const f32x16& t, int q) -> f32x4 {
+    f32x4 al = z;                                        // PReLU slopes: loaded at the point of use (registers are scarce)
+    if (ACT < 0 && p.alpha && nbase + 8 * q + 4 * h < p.N) al = *reinterpret_cast<const f32x4*>(p.alpha + nbase + 8 * q + 4 * h);
     f32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = apply_act(fmaf(t[4 * q + i], sc[q][i], sh[q][i]), ACT < 0 ? p.act : ACT, al[q][i]);
+    for (int i = 0; i < 4; ++i) v[i] = apply_act(fmaf(t[4 * q + i], sc[q][i], sh[q][i]), ACT < 0 ? p.act : ACT, al[i]);
     return v;
   };
   if constexpr (FORM == 1) {
@@ -582,41 +627,68 @@ __device__ __forceinline__ void store_wave_tile_n32_att_impl(const GemmArgs& p, 
     for (int hd = hd0; hd < hd1; ++hd) {
       const float wl = (mb + lane < p.M) ? p.pool_w[(int64_t)(mb + lane) * H + hd] : 0.f;   // lane = frame of this pass
       const int oc = p.pool_split ? n : hd * p.N + n;
-      int r = 0;
-      while (r < 64) {
-        const int b = __builtin_amdgcn_readlane(my_utt, r);
-        int re = r + 1;
-        while (re < 64 && __builtin_amdgcn_readlane(my_utt, re) == b) ++re;
-        if (b >= 0) {
-          float s0 = (lane >= r && lane < re) ? wl : 0.f;           // sum of the segment's weights
+      const int u_first = __builtin_amdgcn_readlane(my_utt, 0), u_last = __builtin_amdgcn_readlane(my_utt, 63);
+      if (u_first >= 0 && u_first == u_last) {
+        // all 64 frames of the pass belong to one utterance: fixed trip counts
+        float s0 = wl;
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) s0 += __shfl_xor(s0, o, 64);
-          f32x4 s1 = z;
-          for (int t0 = r & ~7; t0 < re; t0 += 8) {
-            const int t = t0 + rrow;
-            const float wt = __shfl(wl, t & 63, 64);
-            if (t >= r && t < re) s1 += row4(t) * wt;
-          }
-          s1 = groups_sum(s1);
-          const float inv = s0 > 0.f ? 1.0f / s0 : 0.f;
-          const f32x4 mu = s1 * inv;
-          f32x4 m2 = z;
-          for (int t0 = r & ~7; t0 < re; t0 += 8) {
-            const int t = t0 + rrow;
-            const float wt = __shfl(wl, t & 63, 64);
-            if (t >= r && t < re) {
-              const f32x4 d = row4(t) - mu;
-              m2 += d * d * wt;
+        for (int o = 32; o > 0; o >>= 1) s0 += __shfl_xor(s0, o, 64);
+        float wt[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wt[k] = __shfl(wl, k * 8 + rrow, 64);
+        f32x4 s1 = z;
+#pragma unroll 4
+        for (int k = 0; k < 8; ++k) s1 += row4(k * 8 + rrow) * wt[k];
+        s1 = groups_sum(s1);
+        const f32x4 mu = s1 * (s0 > 0.f ? 1.0f / s0 : 0.f);
+        f32x4 m2 = z;
+#pragma unroll 4
+        for (int k = 0; k < 8; ++k) {                   // second sweep of the LDS copy (registers are scarce here)
+          const f32x4 d = row4(k * 8 + rrow) - mu;
+          m2 += d * d * wt[k];
+        }
+        m2 = groups_sum(m2);
+        if (nok && rrow == 0) {
+          const int64_t slot = (int64_t)p.pool_slotbase[u_first] + tile64;
+          *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2) * p.pool_odim + oc) = s1;
+          *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2 + 1) * p.pool_odim + oc) = m2;
+        }
+      } else {
+        int r = 0;
+        while (r < 64) {
+          const int b = __builtin_amdgcn_readlane(my_utt, r);
+          const unsigned long long same = __ballot(my_utt == b) >> r;          // bit 0 = lane r (set)
+          const int re = r + (~same ? __builtin_ctzll(~same) : 64 - r);
+          if (b >= 0) {
+            float s0 = (lane >= r && lane < re) ? wl : 0.f;           // sum of the segment's weights
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s0 += __shfl_xor(s0, o, 64);
+            f32x4 s1 = z;
+            for (int t0 = r & ~7; t0 < re; t0 += 8) {
+              const int t = t0 + rrow;
+              const float wt = __shfl(wl, t & 63, 64);
+              if (t >= r && t < re) s1 += row4(t) * wt;
+            }
+            s1 = groups_sum(s1);
+            const f32x4 mu = s1 * (s0 > 0.f ? 1.0f / s0 : 0.f);
+            f32x4 m2 = z;
+            for (int t0 = r & ~7; t0 < re; t0 += 8) {
+              const int t = t0 + rrow;
+              const float wt = __shfl(wl, t & 63, 64);
+              if (t >= r && t < re) {
+                const f32x4 d = row4(t) - mu;
+                m2 += d * d * wt;
+              }
+            }
+            m2 = groups_sum(m2);
+            if (nok && rrow == 0) {
+              const int64_t slot = (int64_t)p.pool_slotbase[b] + tile64;
+              *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2) * p.pool_odim + oc) = s1;
+              *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2 + 1) * p.pool_odim + oc) = m2;
             }
           }
-          m2 = groups_sum(m2);
-          if (nok && rrow == 0) {
-            const int64_t slot = (int64_t)p.pool_slotbase[b] + tile64;
-            *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2) * p.pool_odim + oc) = s1;
-            *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2 + 1) * p.pool_odim + oc) = m2;
-          }
+          r = re;
         }
-        r = re;
       }
     }
     wave_lds_sync();

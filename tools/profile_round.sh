@@ -1,21 +1,24 @@
 # Collect the round's evidence on the GPU box: bench lines (default bf16x3 + exact f32 + the other configs),
 # rocprofv3 kernel trace/stats of the same command, PMC passes (separate runs, kernel-trace only).
 # usage: bash tools/profile_round.sh <tag>    -> gpurun_out/<tag>/
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 step() { echo "$(date +%T) $*" >> $out/progress.txt; }
 step bench; python bench.py > $out/bench_bf16x3.json 2> $out/bench_bf16x3.err
-step f32; python bench.py --precision f32 --cpu-seconds 0 > $out/bench_f32.json 2> $out/bench_f32.err
-step att; python bench.py --pooling self_attention --cpu-seconds 0 > $out/bench_att_bf16x3.json 2> $out/bench_att.err
-step varlen; python bench.py --varlen --cpu-seconds 0 > $out/bench_varlen_bf16x3.json 2> $out/bench_varlen.err
-step etdnn; python bench.py --network extended_tdnn --cpu-seconds 0 > $out/bench_etdnn_bf16x3.json 2> $out/bench_etdnn.err
-step resnet; python bench.py --network resnet_18 --batch 64 --dim 40 --cpu-seconds 4 > $out/bench_resnet18_bf16x3.json 2> $out/bench_resnet.err
-step trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --cpu-seconds 0 > $out/trace.log 2>&1
-step pmc_sq; timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -- python bench.py --cpu-seconds 0 --steps 3 --warmup 1 --no-profile > $out/pmc_sq.log 2>&1
-step pmc_fetch; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py --cpu-seconds 0 --steps 3 --warmup 1 --no-profile > $out/pmc_fetch.log 2>&1
-step pmc_write; timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py --cpu-seconds 0 --steps 3 --warmup 1 --no-profile > $out/pmc_write.log 2>&1
+step f32; python bench.py --precision f32 --cpu-seconds 0 --no-extra > $out/bench_f32.json 2> $out/bench_f32.err
+step att; python bench.py --pooling self_attention --cpu-seconds 0 --no-extra > $out/bench_att_bf16x3.json 2> $out/bench_att.err
+step varlen; python bench.py --varlen --cpu-seconds 0 --no-extra > $out/bench_varlen_bf16x3.json 2> $out/bench_varlen.err
+step etdnn; python bench.py --network extended_tdnn --cpu-seconds 0 --no-extra > $out/bench_etdnn_bf16x3.json 2> $out/bench_etdnn.err
+step resnet; python bench.py --network resnet_18 --batch 64 --dim 40 --cpu-seconds 4 --no-extra > $out/bench_resnet18_bf16x3.json 2> $out/bench_resnet.err
+step trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --cpu-seconds 0 --no-extra > $out/trace.log 2>&1
+step pmc_sq; timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -- python bench.py --cpu-seconds 0 --no-extra --steps 3 --warmup 1 --no-profile > $out/pmc_sq.log 2>&1
+step pmc_fetch; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py --cpu-seconds 0 --no-extra --steps 3 --warmup 1 --no-profile > $out/pmc_fetch.log 2>&1
+step pmc_write; timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py --cpu-seconds 0 --no-extra --steps 3 --warmup 1 --no-profile > $out/pmc_write.log 2>&1
+step trace_att; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_att -- python bench.py --pooling self_attention --cpu-seconds 0 --no-extra > $out/trace_att.log 2>&1
+python profiles/summarize_trace.py $(find $out/trace_att -name "*kernel_trace.csv" | head -1) > $out/per_layer_summary_att.txt 2>&1
+rm -rf $out/trace_att
 step summarise
 python profiles/summarize_trace.py $(find $out/trace -name "*kernel_trace.csv" | head -1) > $out/per_layer_summary.txt 2>&1
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
