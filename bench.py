@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 FLOP_PER_UTT_300 = 2452865024          # BASELINE.md section 2 (L1..L6, T=300)
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0}   # MI355X_MICROARCH.md: fp32 MFMA / bf16 MFMA dense
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0}   # MI355X_MICROARCH.md: fp32 MFMA / bf16 = f16 MFMA dense
 HBM_PEAK_GBS = 8000.0
 
 
@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--dim", type=int, default=30)
-    ap.add_argument("--precision", default=os.environ.get("XVEC_PRECISION", ""), help="f32 | bf16x3 (default: library default)")
+    ap.add_argument("--precision", default=os.environ.get("XVEC_PRECISION", ""), help="f32 | bf16x3 | f16x3 (default: library default)")
     ap.add_argument("--pooling", default="statistics_pooling", choices=["statistics_pooling", "self_attention"])
     ap.add_argument("--network", default="tdnn", choices=["tdnn", "extended_tdnn", "resnet_18"],
                     help="tdnn = BASELINE configs 1-4; resnet_18 = config 5 (use --dim 40 --batch 64)")
@@ -71,7 +71,7 @@ def pmc_traffic(kernel, precision, args):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
     command (profiles/<round>/traffic.json; FETCH_SIZE/WRITE_SIZE need their own profiler runs, so
     they cannot be sampled inside the timed region).  None when no matching profile exists."""
-    if (precision != "bf16x3" or args.varlen or args.pooling != "statistics_pooling" or args.batch != 256 or
+    if (precision == "f32" or args.varlen or args.pooling != "statistics_pooling" or args.batch != 256 or
             args.frames != 300 or args.network != "tdnn"):
         return None
     import glob
@@ -398,9 +398,9 @@ def main():
             roof["algorithmic_bytes"] = dom["bytes"]
             if dominant and dominant[0]["name"] == dom["name"]:
                 roof["launch_ms_value_region"] = round(dominant[0]["ms"], 4)
-            if precision == "bf16x3":
+            if precision != "f32":
                 roof["mfma_issue_frac"] = round(3 * tf / peak, 4)
-                roof["note"] = ("bf16x3: 3 bf16 MFMAs per algorithmic product, so the ceiling of `frac` is 1/3; "
+                roof["note"] = ("split precision: 3 MFMAs per algorithmic product, so the ceiling of `frac` is 1/3; "
                                 "mfma_issue_frac = issued MFMA FLOPs / bf16 dense peak")
         flops_step = float(info["flops"])
         result = {
@@ -408,7 +408,7 @@ def main():
             "value": round(value, 1), "unit": "utterances/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if precision == "f32" else "bf16x3(f32-split)", "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x3": "bf16x3(f32-split)", "f16x3": "f16x3(f32-split)"}[precision], "data": "synthetic",
             "config": {"workload": "%s x-vector (%s), %s, %d utt/GPU/step of %s frames x %d dims"
                        % (args.network, params.embedding_node, args.pooling, args.batch,
                           "U[200,1000]" if args.varlen else str(args.frames), args.dim),

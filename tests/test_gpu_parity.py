@@ -37,7 +37,7 @@ def stat_model():
     return params, weights
 
 
-PRECISIONS = ["f32", "bf16x3"]
+PRECISIONS = ["f32", "bf16x3", "f16x3"]
 _report = []
 
 
@@ -153,7 +153,7 @@ def test_extended_tdnn_every_endpoint(precision, pooling):
     tr.close()
 
 
-@pytest.mark.parametrize("width,precision", [(8, "f32"), (32, "f32"), (32, "bf16x3")])
+@pytest.mark.parametrize("width,precision", [(8, "f32"), (32, "f32"), (32, "bf16x3"), (32, "f16x3")])
 def test_resnet18_every_block(width, precision):
     """network_type "resnet_18" (model/resnet.py:152-351) block by block on a ragged batch; width 8 runs the
     fp32 kernels with 24-wide taps, width 32 the split kernel on whole SB blocks."""

@@ -45,7 +45,7 @@ def test_random_ragged_batches(seed):
     nutt = int(rng.integers(1, 12))
     lens = [int(x) for x in rng.choice([15, 16, 17, 31, 64, 127, 128, 129, 200, 333], size=nutt)]
     utts = synth.synth_features(nutt, lens, 30, seed=seed + 50)
-    for precision in ("bf16x3", "f32"):
+    for precision in ("bf16x3", "f16x3", "f32"):
         tr = _trainer(params, weights, 30, precision)
         got = tr.predict_list(utts)
         for i, u in enumerate(utts):
@@ -172,6 +172,35 @@ def test_fused_attention_path_matches_unfused_and_exact(kw):
     for i in (0, 3, 7):                                               # and against the float64 oracle
         ref = ref_numpy.predict(utts[i], weights, params, 30)
         assert _rel(fused["tdnn6_dense"][i], ref) <= TOL, (i, kw)
+
+
+def test_f16x3_is_tighter_than_bf16x3_and_reports_overflow():
+    """The fp16 hi/lo split format (XV_PREC_F16X3): same kernels and layout as bf16x3, 22 instead of 16 significand bits.
+    At the BASELINE geometry its embeddings and its (peaky) attention weights must be several times closer to the exact
+    fp32 path than bf16x3's; and a feature beyond the fp16 range must surface as an error, not as a NaN embedding."""
+    from tf_kaldi_speaker_amd import synth
+    params = dict(synth.TDNN_ATT_PARAMS)
+    weights = synth.synth_weights(params, 30, seed=2)
+    weights["tdnn/attention/query"] = weights["tdnn/attention/query"] * 1000.0          # peaky attention (test_gpu_parity)
+    utts = synth.synth_features(8, 300, 30, seed=12)
+    feats = np.stack(utts)
+    res = {}
+    for prec in ("f32", "bf16x3", "f16x3"):
+        tr = _trainer(params, weights, 30, prec)
+        res[prec] = {}
+        for node in ("attention_weights", "tdnn6_dense"):
+            tr.set_embedding(node)
+            res[prec][node] = tr.predict(feats).astype(np.float64)
+        if prec == "f16x3":
+            bad = feats.copy()
+            bad[3, 100, 7] = 1.0e5
+            with pytest.raises(FloatingPointError):
+                tr.predict(bad)
+        tr.close()
+    for node in ("attention_weights", "tdnn6_dense"):
+        e16 = _rel2(res["f16x3"][node], res["f32"][node])
+        ebf = _rel2(res["bf16x3"][node], res["f32"][node])
+        assert e16 <= 2e-5 and e16 * 4 <= ebf, (node, e16, ebf)
 
 
 def test_vmcnt_retires_in_issue_order(tmp_path, repo_root):

@@ -352,7 +352,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
 // EPI selects the epilogue at compile time: 0 = activations (fp32 / SB / residual / fused statistics pooling),
 // 1 / 2 = the attention forms of xv_epilogue.h (score partials of the last key layer / weighted moments of the value).
 // A separate instantiation keeps the default kernel's code -- and its register allocation -- untouched.
-template <int NPS, int EPI = 0>
+// F16 selects the split format of both operands (bf16 hi/lo or fp16 hi/lo: same bytes, same MFMA rate).
+template <int NPS, int EPI = 0, bool F16 = false>
 __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, int w, char* smem3, int cb_begin, int cb_end) {
   char* As = smem3;
   const int tid = threadIdx.x;
@@ -448,9 +449,9 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
       if (g == 4) XV_WAIT2(7 + 2 * NPS, Wc[1], Wc[3]);
       const int ks = g >> 2, mi = g & 3;
       const bf16x8 wh = Wc[ks], wl = Wc[2 + ks];
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, fl[g], acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, fh[g], acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, fh[g], acc[mi], 0, 0, 0);
+      acc[mi] = mfma_split<F16>(wh, fl[g], acc[mi]);
+      acc[mi] = mfma_split<F16>(wl, fh[g], acc[mi]);
+      acc[mi] = mfma_split<F16>(wh, fh[g], acc[mi]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (cb1 != cb) {                     // slab switch
@@ -476,22 +477,22 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
   __builtin_amdgcn_sched_barrier(0);
   stamp(2);
   if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
-  else store_wave_tile_n32<64>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
+  else store_wave_tile_n32<64, F16>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
   stamp(3);
 }
 
-template <int NPS, int EPI = 0>
+template <int NPS, int EPI = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_kernel(GemmArgs p, int nMt, int nNt, int w) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   const int tile = xcd_remap(blockIdx.x, nMt * nNt);
   const int mt = tile / nNt, nt = tile - mt * nNt;
-  w14p2_tile<NPS, EPI>(p, mt * BM, nt * BN, w, smem3, 0, (p.Kpad >> 5) / w);
+  w14p2_tile<NPS, EPI, F16>(p, mt * BM, nt * BN, w, smem3, 0, (p.Kpad >> 5) / w);
 }
 
 // K-split form for the M tiles of the last, nearly empty round (gemm_bf16x3_tail_plan): workgroup = (tile, slice);
 // slice s accumulates channel blocks [s * ncb / S, (s + 1) * ncb / S) and stores its RAW accumulators to
 // partial[s][row - mt0 * 128][Npad]; bf16x3_tail_reduce_kernel adds the slices in order and runs the epilogue.
-template <int NPS>
+template <int NPS, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_tail_kernel(GemmArgs p, int mt0, int nNt, int w, int S) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   const int split = blockIdx.x % S, tile = blockIdx.x / S;
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_tail_kernel(GemmArgs
   q.rowmap = nullptr;
   q.R = nullptr;
   q.pool_part = nullptr;
-  w14p2_tile<NPS>(q, mt * BM, nt * BN, w, smem3, split * per, (split + 1) * per);
+  w14p2_tile<NPS, 0, F16>(q, mt * BM, nt * BN, w, smem3, split * per, (split + 1) * per);
 }
 
 // one thread per (tail row, 4 channels): ordered sum of the K slices, then the usual epilogue (BN scale/shift,
@@ -534,8 +535,8 @@ __global__ void bf16x3_tail_reduce_kernel(GemmArgs p, int mt0, int S) {
     if (p.Y && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;     // N % 4 == 0 (wide epilogue)
     if (p.Ysb && n < p.ldsb) {
       uint32_t h01, l01, h23, l23;
-      split2(v[0], v[1], h01, l01);
-      split2(v[2], v[3], h23, l23);
+      split2(v[0], v[1], h01, l01, p.f16);
+      split2(v[2], v[3], h23, l23, p.f16);
       char* blk = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128 + (n & 31) * 2;
       *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
       *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
@@ -609,24 +610,18 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
   {
     std::lock_guard<std::mutex> init_lock(init_mu);
     if (!attr_set[dev & 63]) {
-      hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-      if (r != hipSuccess) return r;
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-      if (r != hipSuccess) return r;
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-      if (r != hipSuccess) return r;
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-      if (r != hipSuccess) return r;
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-      if (r != hipSuccess) return r;
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
-      if (r != hipSuccess) return r;
+      const void* kernels[] = {
+          reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1, 0, false>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 0, false>),
+          reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 1, false>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 2, false>),
+          reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<1, false>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<4, false>),
+          reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1, 0, true>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 0, true>),
+          reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 1, true>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 2, true>),
+          reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<1, true>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<4, true>)};
+      hipError_t r = hipSuccess;
+      for (const void* k : kernels) {
+        r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+        if (r != hipSuccess) return r;
+      }
 #ifdef XV_LAB
       const char* e = getenv("XVEC_GEMM_TILE");
       force = e ? atoi(e) : 0;
@@ -658,26 +653,43 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
   if (!taps_ok) return hipErrorInvalidValue;   // the plan only routes layers of <= 9 taps and whole 32-channel blocks here
   // 1 x 4 waves, weights in registers two steps ahead.  Tail handling is decided at plan time (the plan owns the
   // partial workspace): the last tail_mt M tiles go K-split
+  const dim3 block(256);
   if (a.att_part || a.pool_w) {                 // attention epilogue: dense layers without row compaction only
     if (w != 1 || a.rowmap || a.a_pitch || a.R || (a.N & 3) || (a.pool_w && !a.pool_part)) return hipErrorInvalidValue;
-    if (a.att_part) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 1>), dim3(nMt * nNt), dim3(256), smemw32, s, a, nMt, nNt, w);
-    else            hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 2>), dim3(nMt * nNt), dim3(256), smemw32, s, a, nMt, nNt, w);
+    const dim3 grid(nMt * nNt);
+    if (a.att_part) {
+      if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 1, true>), grid, block, smemw32, s, a, nMt, nNt, w);
+      else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 1, false>), grid, block, smemw32, s, a, nMt, nNt, w);
+    } else {
+      if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 2, true>), grid, block, smemw32, s, a, nMt, nNt, w);
+      else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 2, false>), grid, block, smemw32, s, a, nMt, nNt, w);
+    }
     return hipGetLastError();
   }
   const bool tail = a.tail_mt > 0 && a.ksplit > 1 && a.partial && !a.a_pitch && !a.pool_part && !a.R && !a.raw &&
                     a.tail_mt < nMt && (a.N & 3) == 0;
   const int nMain = tail ? nMt - a.tail_mt : nMt;
-  const dim3 grid(nMain * nNt), block(256);
+  const dim3 grid(nMain * nNt);
 #ifdef XV_GEMM_TRACE
   if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
 #endif
-  if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1>), grid, block, smemw32, s, a, nMain, nNt, w);
-  else        hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4>), grid, block, smemw32, s, a, nMain, nNt, w);
+  if (w >= 5) {
+    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 0, true>), grid, block, smemw32, s, a, nMain, nNt, w);
+    else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 0, false>), grid, block, smemw32, s, a, nMain, nNt, w);
+  } else {
+    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 0, true>), grid, block, smemw32, s, a, nMain, nNt, w);
+    else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 0, false>), grid, block, smemw32, s, a, nMain, nNt, w);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || !tail) return e;
   const dim3 tgrid(a.tail_mt * nNt * a.ksplit);
-  if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<1>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
-  else        hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<4>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
+  if (w >= 5) {
+    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<1, true>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
+    else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<1, false>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
+  } else {
+    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<4, true>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
+    else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<4, false>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int64_t total = (int64_t)a.tail_mt * BM * (a.Npad >> 2);

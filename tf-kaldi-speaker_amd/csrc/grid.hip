@@ -57,7 +57,7 @@ __global__ void rowmap_interior_kernel(const int32_t* __restrict__ off0, int B, 
 // conv0 (3x3, cin = 1): one thread per (output grid position, pair of taps); taps 9..31 are zero padding
 template <bool SB>
 __global__ void im2col2d_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ off0, int B, int F,
-                                int64_t P, char* __restrict__ out) {
+                                int64_t P, char* __restrict__ out, int f16) {
   const int64_t total = P * 16;
   const int S = F + 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -78,7 +78,7 @@ __global__ void im2col2d_kernel(const float* __restrict__ x, int64_t ldx, const 
     }
     if (SB) {
       uint32_t hi, lo;
-      split2(v[0], v[1], hi, lo);
+      split2(v[0], v[1], hi, lo, f16);
       char* blk = out + p * 128 + k * 2;
       *reinterpret_cast<uint32_t*>(blk) = hi;
       *reinterpret_cast<uint32_t*>(blk + 64) = lo;
@@ -134,10 +134,10 @@ hipError_t launch_build_rowmap_interior(const int32_t* off0, int B, int F, int32
 }
 
 hipError_t launch_im2col2d_sb(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int64_t P, void* out_sb,
-                              hipStream_t s) {
+                              int f16, hipStream_t s) {
   if (P <= 0) return hipSuccess;
   hipLaunchKernelGGL(im2col2d_kernel<true>, dim3(launch_blocks(P * 16)), dim3(256), 0, s, x, ldx, off0, B, F, P,
-                     static_cast<char*>(out_sb));
+                     static_cast<char*>(out_sb), f16);
   return hipGetLastError();
 }
 
@@ -145,7 +145,7 @@ hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0,
                                hipStream_t s) {
   if (P <= 0) return hipSuccess;
   hipLaunchKernelGGL(im2col2d_kernel<false>, dim3(launch_blocks(P * 16)), dim3(256), 0, s, x, ldx, off0, B, F, P,
-                     reinterpret_cast<char*>(out));
+                     reinterpret_cast<char*>(out), 0);
   return hipGetLastError();
 }
 

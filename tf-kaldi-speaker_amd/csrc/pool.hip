@@ -1,11 +1,10 @@
 // HBM-bound kernels of the x-vector path: statistics pooling, attentive pooling, row maps,
 // l2 scaling and small elementwise stages.  All are wavefront(64)-shaped reductions:
 // coalesced 16-byte loads, DPP/shuffle reduction inside a wave, one LDS hop across waves.
-#include "xv_kernels.h"
+#include "xv_epilogue.h"
 
 namespace xv {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float act_apply(float v, int act, float alpha) {
   switch (act) {
@@ -404,7 +403,7 @@ hipError_t launch_att_weights_out(const float* scores, int H, const int32_t* off
 // One thread per (row, pair of k): the 30-dim input is tiny (36 KB/utterance), so materialising
 // the w*cin-wide rows once lets the first layer run on the bf16x3 MFMA kernel as a dense layer.
 __global__ void im2col_sb_kernel(const float* __restrict__ x, int64_t ldx, int cin, int K, int64_t rows,
-                                 char* __restrict__ out, int ldsb) {
+                                 char* __restrict__ out, int ldsb, int f16) {
   const int pairs = ldsb >> 1;
   const int64_t total = rows * pairs;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -417,26 +416,21 @@ __global__ void im2col_sb_kernel(const float* __restrict__ x, int64_t ldx, int c
       const int dr = kk / cin;
       v[e] = kk < K ? x[(m + dr) * ldx + (kk - dr * cin)] : 0.f;
     }
-    // hi/lo split (round to nearest even), same arithmetic as xv_epilogue.h split2
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 vv = {v[0], v[1]};
-    const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(vv, bf2));
-    const f2 hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
-    const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(vv - hf, bf2));
+    uint32_t hi, lo;
+    split2(v[0], v[1], hi, lo, f16);                 // hi/lo split in the format the GEMM consumes (xv_epilogue.h)
     char* blk = out + m * (int64_t)ldsb * 4 + (k >> 5) * 128 + (k & 31) * 2;
     *reinterpret_cast<uint32_t*>(blk) = hi;
     *reinterpret_cast<uint32_t*>(blk + 64) = lo;
   }
 }
 
-hipError_t launch_im2col_sb(const float* x, int64_t ldx, int cin, int w, int64_t rows, void* out_sb, int ldsb,
+hipError_t launch_im2col_sb(const float* x, int64_t ldx, int cin, int w, int64_t rows, void* out_sb, int ldsb, int f16,
                             hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   const int64_t total = rows * (ldsb >> 1);
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(im2col_sb_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, cin, w * cin, rows,
-                     static_cast<char*>(out_sb), ldsb);
+                     static_cast<char*>(out_sb), ldsb, f16);
   return hipGetLastError();
 }
 

@@ -40,13 +40,39 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha) {
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-// hi/lo bf16 split of two fp32 values, packed {a | b << 16}: v_cvt_pk_bf16_f32 (RNE, NaN-safe),
-// shl/and, v_pk_add_f32, v_cvt_pk_bf16_f32 = 2.5 VALU instructions per value.
-__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// hi/lo split of two fp32 values, packed {a | b << 16}.
+//  bf16 (F16 = false): v_cvt_pk_bf16_f32 (RNE, NaN-safe), shl/and, v_pk_add_f32, v_cvt_pk_bf16_f32 = 2.5 VALU per value;
+//        hi + lo carries 16 significand bits over the full fp32 range.
+//  fp16 (F16 = true):  hi = rn_f16(x), lo = rn_f16(x - hi): 22 significand bits for |x| in [2^-3, 65504]; below that the
+//        low half goes subnormal (absolute error <= 2^-25), above it the value overflows to inf (the host checks).
+template <bool F16>
+__device__ __forceinline__ void split2t(float a, float b, uint32_t& hi, uint32_t& lo) {
   const f32x2_t v = {a, b};
-  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-  const f32x2_t hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
-  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - hf, bf16x2_t));
+  if constexpr (F16) {
+    const f16x2_t hh = __builtin_convertvector(v, f16x2_t);
+    hi = __builtin_bit_cast(uint32_t, hh);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - __builtin_convertvector(hh, f32x2_t), f16x2_t));
+  } else {
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    const f32x2_t hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - hf, bf16x2_t));
+  }
+}
+// run-time form for the kernels off the hot path (f16 is uniform over the launch)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo, int f16) {
+  if (f16) split2t<true>(a, b, hi, lo); else split2t<false>(a, b, hi, lo);
+}
+
+// one product tile of the split GEMM: v_mfma_f32_32x32x16_bf16 or _f16 (same rate, same fragment layout)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_split(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // XCD-aware bijective remap of a 1-D grid (ids congruent mod 8 share an XCD and its L2).
@@ -84,7 +110,7 @@ __device__ __forceinline__ void store_tile_scalar(const GemmArgs& p, const f32x1
     if (p.Y && nok) p.Y[(int64_t)orow * p.ldy + n] = v;
     if (p.Ysb && n < p.ldsb) {
       uint32_t hi, lo;
-      split2(v, 0.f, hi, lo);
+      split2(v, 0.f, hi, lo, p.f16);
       uint16_t* blk = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128);
       blk[n & 31] = (uint16_t)hi;
       blk[32 + (n & 31)] = (uint16_t)lo;
@@ -192,8 +218,8 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
         }
         if (p.Ysb && n < p.ldsb) {
           uint32_t h01, l01, h23, l23;
-          split2(v[0], v[1], h01, l01);
-          split2(v[2], v[3], h23, l23);
+          split2(v[0], v[1], h01, l01, p.f16);
+          split2(v[2], v[3], h23, l23, p.f16);
           char* blk = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128 + (n & 31) * 2;
           *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
           *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
@@ -217,8 +243,8 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
           for (int ml = 0; ml < MIP; ++ml) {
             const f32x4 v = value4(acc[ni][ps * MIP + ml], q, sc, sh, al);
             uint32_t h01, l01, h23, l23;
-            split2(v[0], v[1], h01, l01);
-            split2(v[2], v[3], h23, l23);
+            split2(v[0], v[1], h01, l01, p.f16);
+            split2(v[2], v[3], h23, l23, p.f16);
             const int row = ml * 32 + r32;
             char* rp = scratch + row * 256 + 8 * h;
             *reinterpret_cast<uint2*>(rp + (((ni * 8 + q) ^ (row & 15)) << 4)) = make_uint2(h01, h23);
@@ -321,7 +347,7 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
 // (128 bytes) or 32 floats, so the scratch rows are 128 bytes (8 chunks, XOR-swizzled by frame & 7) and the
 // read-back hands 8 lanes one whole 128-byte line.  ROWS frames per pass (ROWS * 128 bytes of scratch per wave);
 // the fused statistics pooling needs ROWS == 64 (its partial slots are per 64-frame tile).
-template <int ACT, int ROWS>
+template <int ACT, int ROWS, bool F16>
 __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
                                                          int lane, int wave, char* lds) {
   static_assert(ROWS == 32 || ROWS == 64 || ROWS == 128, "ROWS");
@@ -393,8 +419,8 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
         }
         if (p.Ysb && n < p.ldsb) {
           uint32_t h01, l01, h23, l23;
-          split2(v[0], v[1], h01, l01);
-          split2(v[2], v[3], h23, l23);
+          split2t<F16>(v[0], v[1], h01, l01);
+          split2t<F16>(v[2], v[3], h23, l23);
           char* blk = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128 + (n & 31) * 2;
           *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
           *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
@@ -414,8 +440,8 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
         for (int q = 0; q < 4; ++q) {
           const f32x4 v = value4(acc[ps * MIP + ml], q, false);   // padding channels: scale = shift = 0 -> 0
           uint32_t h01, l01, h23, l23;
-          split2(v[0], v[1], h01, l01);
-          split2(v[2], v[3], h23, l23);
+          split2t<F16>(v[0], v[1], h01, l01);
+          split2t<F16>(v[2], v[3], h23, l23);
           const int row = ml * 32 + r32;
           char* rp = scratch + row * 128 + 8 * h;
           *reinterpret_cast<uint2*>(rp + ((q ^ (row & 7)) << 4)) = make_uint2(h01, h23);
@@ -707,7 +733,7 @@ __device__ __forceinline__ void store_wave_tile_n32_att(const GemmArgs& p, const
 }
 
 // Epilogue entry for the 128x32 wave tile.
-template <int ROWS>
+template <int ROWS, bool F16>
 __device__ __forceinline__ void store_wave_tile_n32(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
                                                     int lane, int wave, char* lds);
 
@@ -738,16 +764,16 @@ __device__ __forceinline__ void store_wave_tile(const GemmArgs& p, const f32x16 
     for (int mi = 0; mi < MI; ++mi) store_tile_scalar(p, acc[ni][mi], mbase + mi * 32, nbase + ni * 32, lane);
 }
 
-template <int ROWS>
+template <int ROWS, bool F16>
 __device__ __forceinline__ void store_wave_tile_n32(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
                                                     int lane, int wave, char* lds) {
   if (wide_epilogue_ok(p)) {
     if (p.act == ACT_RELU)
-      store_wave_tile_n32_impl<ACT_RELU, ROWS>(p, acc, mbase, nbase, lane, wave, lds);
+      store_wave_tile_n32_impl<ACT_RELU, ROWS, F16>(p, acc, mbase, nbase, lane, wave, lds);
     else if (p.act == ACT_NONE)
-      store_wave_tile_n32_impl<ACT_NONE, ROWS>(p, acc, mbase, nbase, lane, wave, lds);
+      store_wave_tile_n32_impl<ACT_NONE, ROWS, F16>(p, acc, mbase, nbase, lane, wave, lds);
     else
-      store_wave_tile_n32_impl<-1, ROWS>(p, acc, mbase, nbase, lane, wave, lds);
+      store_wave_tile_n32_impl<-1, ROWS, F16>(p, acc, mbase, nbase, lane, wave, lds);
     return;
   }
 #pragma unroll

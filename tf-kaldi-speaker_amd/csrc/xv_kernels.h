@@ -41,6 +41,8 @@ struct GemmArgs {
   int ldsb;               // channels per SB output row incl. zero padding (multiple of 32)
   const void* Wsb;        // packed weights in SB format [Npad][Kpad/32][128 bytes]
   const void* Wfr = nullptr;   // weights, MFMA-fragment-major (gemm_bf16x3_wreg_kernel)
+  int f16 = 0;                 // split format of both operands: 0 = bf16 hi/lo (bf16x3), 1 = fp16 hi/lo (f16x3: same layout and
+                               // MFMA rate, 11 + 11 significand bits instead of 8 + 8; values beyond +-65504 overflow)
   long long* trace = nullptr;  // debug: per-workgroup phase timestamps (XVEC_TRACE_K), 4 per workgroup
   // split-K (fp32 kernel, small-M segment layers): slice s of `ksplit` accumulates K tiles
   // [s*kper, (s+1)*kper) and writes RAW accumulators to partial[s][M][Npad]; a reduce kernel
@@ -106,7 +108,7 @@ int64_t gemm_bf16x3_tail_plan(int M, int Kpad, int Npad, int w, int* tail_mt, in
 
 // fp32 frames -> split-blocked im2col rows for a small-cin first layer:
 //   out row m, k < w*cin: x[(m + k / cin) * ldx + k % cin]; zero padded to ldsb columns.
-hipError_t launch_im2col_sb(const float* x, int64_t ldx, int cin, int w, int64_t rows, void* out_sb, int ldsb,
+hipError_t launch_im2col_sb(const float* x, int64_t ldx, int cin, int w, int64_t rows, void* out_sb, int ldsb, int f16,
                             hipStream_t s);
 
 // bf16x3 split path (3x v_mfma_f32_32x32x16_bf16 per product tile).
@@ -141,7 +143,7 @@ hipError_t launch_build_rowmap_rows(const int32_t* off0, int B, int32_t* rowmap,
 hipError_t launch_build_rowmap_interior(const int32_t* off0, int B, int F, int32_t* rowmap, int64_t M, hipStream_t s);
 // conv0 im2col: out SB row p (grid position of the OUTPUT), k = kh*3+kw < 9: x[t+kh-1][f+kw-1] or 0
 hipError_t launch_im2col2d_sb(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int64_t P, void* out_sb,
-                              hipStream_t s);
+                              int f16, hipStream_t s);
 hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int64_t P, float* out,
                                hipStream_t s);
 // grid [P, C] -> dense [sum L_b * F, C] (drops the zero border; test / endpoint output only)

@@ -290,6 +290,17 @@ float bf16_to_f32(uint16_t b) {
   memcpy(&f, &u, 4);
   return f;
 }
+uint16_t f32_to_f16_rn(float f) {    // IEEE binary16, round to nearest even (subnormals kept, overflow -> inf)
+  const _Float16 h = (_Float16)f;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+float f16_to_f32(uint16_t u) {
+  _Float16 h;
+  memcpy(&h, &u, 2);
+  return (float)h;
+}
 
 void expect(xv_handle* h, const std::string& name, std::vector<int64_t> shape) {
   HostTensor t;
@@ -621,15 +632,40 @@ int upload_layer(xv_handle* h, Layer& L) {
     XV_HIP(h, hipMemcpy(L.wt.p, wt.data(), elems * sizeof(float), hipMemcpyHostToDevice));
   } else {
     // split-blocked: row n, block kb: [32 x hi | 32 x lo] for k = 32*kb .. 32*kb+31 (xv_epilogue.h)
+    const bool f16 = h->desc.precision == XV_PREC_F16X3;
+    float wscale = 1.f;
+    if (f16) {
+      // fp16 hi/lo keeps 22 significand bits only while the low half stays normal (|w * s| >= 2^-3): scale the layer's
+      // weights by a power of two so that the largest lands in [8192, 16384); the epilogue's per-channel scale
+      // (and the "ones" vector of the affine-stage endpoints) absorbs 1/s exactly
+      float maxabs = 0.f;
+      for (size_t i = 0; i < (size_t)K * N; ++i) maxabs = std::max(maxabs, std::fabs(W[i]));
+      if (maxabs > 0.f && std::isfinite(maxabs)) {
+        int e = 0;
+        std::frexp(maxabs, &e);                     // maxabs = m * 2^e, m in [0.5, 1)
+        wscale = std::ldexp(1.f, std::min(std::max(14 - e, -24), 24));
+      }
+    }
     std::vector<uint16_t> sb(elems * 2, 0);
     for (int k = 0; k < K; ++k)
       for (int n = 0; n < N; ++n) {
-        const float wv = W[(size_t)k * N + n];
-        const uint16_t a = f32_to_bf16_rn(wv);
+        const float wv = W[(size_t)k * N + n] * wscale;
         const size_t blk = ((size_t)n * (L.Kpad / 32) + k / 32) * 64;
-        sb[blk + (k & 31)] = a;
-        sb[blk + 32 + (k & 31)] = f32_to_bf16_rn(wv - bf16_to_f32(a));
+        if (f16) {
+          const uint16_t a = f32_to_f16_rn(wv);
+          sb[blk + (k & 31)] = a;
+          sb[blk + 32 + (k & 31)] = f32_to_f16_rn(wv - f16_to_f32(a));
+        } else {
+          const uint16_t a = f32_to_bf16_rn(wv);
+          sb[blk + (k & 31)] = a;
+          sb[blk + 32 + (k & 31)] = f32_to_bf16_rn(wv - bf16_to_f32(a));
+        }
       }
+    if (wscale != 1.f) {                             // fold 1/s into [bn_scale | ones]; bias / shift are not products
+      const float inv = 1.f / wscale;
+      for (int n = 0; n < N; ++n) { vec[(size_t)N + n] *= inv; vec[(size_t)4 * N + n] *= inv; }
+      XV_HIP(h, hipMemcpy(L.vec.p, vec.data(), vec.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     XV_HIP(h, L.wsb.alloc(elems * 4));
     XV_HIP(h, hipMemcpy(L.wsb.p, sb.data(), elems * 4, hipMemcpyHostToDevice));
     // fragment-major copy for the weights-in-registers kernel: one global_load_dwordx4 of a wave = 1 KB contiguous
@@ -690,7 +726,7 @@ int xv_create(const xv_model_desc* desc, int device, xv_handle** out) {
         return fail(nullptr, XV_ERR_INVALID, "xv_create: resnet_blocks[%d] = %d", i, desc->resnet_blocks[i]);
   if (desc->feat_dim < 1 || desc->channels < 1 || desc->num_nodes_pooling_layer < 1 || desc->num_nodes_last_layer < 1)
     return fail(nullptr, XV_ERR_INVALID, "xv_create: non-positive layer width");
-  if (desc->precision != XV_PREC_F32 && desc->precision != XV_PREC_BF16X3)
+  if (desc->precision != XV_PREC_F32 && desc->precision != XV_PREC_BF16X3 && desc->precision != XV_PREC_F16X3)
     return fail(nullptr, XV_ERR_INVALID, "xv_create: unknown precision %d", desc->precision);
   if (desc->relu_type < XV_ACT_RELU || desc->relu_type > XV_ACT_PRELU)
     return fail(nullptr, XV_ERR_INVALID, "xv_create: unknown relu_type %d", desc->relu_type);
@@ -748,7 +784,7 @@ int xv_finalize(xv_handle* h) {
     if (op.kind != OP_GEMM) continue;
     Layer& L = h->layers[op.layer];
     const Value& vin = h->values[op.in0];
-    const bool bf = h->desc.precision == XV_PREC_BF16X3;
+    const bool bf = h->desc.precision != XV_PREC_F32;       // a split format: bf16x3 or f16x3
     if (L.mode == 0) {
       L.im2col = bf && op.in0 == 0;
       L.use_split = L.im2col || (bf && vin.frame_level && (L.w == 1 || (L.cin % 32 == 0 && L.w <= 9)));   // slab halo of the split kernel
@@ -1249,7 +1285,8 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
   const int B = p->info.batch;
   const int32_t* off = static_cast<const int32_t*>(p->d_offsets.p);
   const xv_model_desc& d = h->desc;
-  const bool split = d.precision == XV_PREC_BF16X3;
+  const bool split = d.precision != XV_PREC_F32;
+  const int f16 = d.precision == XV_PREC_F16X3;
 
   bool prof = false;
   size_t prof_base = 0;
@@ -1294,6 +1331,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         a.rowmap = st.rowmap >= 0 ? static_cast<const int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.rowmap] : nullptr;
         a.Y = optr; a.ldy = L.cout;
         a.K = L.K();
+        a.f16 = f16;
         const Value& vo = h->values[op.out];
         if (vo.grid_F > 0) {              // zero the border (and everything else) of a grid output first
           if (st.out_off >= 0) XV_HIP(h, hipMemsetAsync(ws + st.out_off, 0, (size_t)st.rows_out * L.cout * 4, s));
@@ -1341,7 +1379,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           if (st.scratch_off < 0) return fail(h, XV_ERR_STATE, "conv0 has no scratch");
           a.cin = 32; a.K = 32;             // taps 9..31 are zero in both operands
           if (L.use_split) {
-            XV_HIP(h, launch_im2col2d_sb(feats, feat_ld, off, B, L.Fout, st.M, ws + st.scratch_off, s));
+            XV_HIP(h, launch_im2col2d_sb(feats, feat_ld, off, B, L.Fout, st.M, ws + st.scratch_off, f16, s));
             a.Xsb = ws + st.scratch_off; a.ldsbx = 32; a.Wsb = L.wsb.p; a.Wfr = L.wfr.p;
             XV_HIP(h, launch_gemm_bf16x3(a, s));
           } else {
@@ -1358,7 +1396,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           // 30-dim first layer on the split kernel: materialise the w*cin-wide rows once (SB
           // format, K padded to 32), then it is a dense layer on those rows
           if (st.scratch_off < 0) return fail(h, XV_ERR_STATE, "im2col layer has no scratch");
-          XV_HIP(h, launch_im2col_sb(feats, feat_ld, L.cin, L.w, st.M, ws + st.scratch_off, L.Kpad, s));
+          XV_HIP(h, launch_im2col_sb(feats, feat_ld, L.cin, L.w, st.M, ws + st.scratch_off, L.Kpad, f16, s));
           a.Xsb = ws + st.scratch_off;
           a.ldsbx = L.Kpad;
           a.cin = a.K;

@@ -42,7 +42,7 @@ def build_parser():
     parser.add_argument("--node", type=str, default="", help="The node to output the embeddings.")
     parser.add_argument("--batch-frames", type=int, default=76800,
                         help="Frames packed into one device batch (extension; 76800 = 256 utterances x 300 frames).")
-    parser.add_argument("--precision", type=str, default="", help="f32 | bf16x3 (extension; default: library default)")
+    parser.add_argument("--precision", type=str, default="", help="f32 | bf16x3 | f16x3 (extension; default: library default)")
     parser.add_argument("--scp-input", action="store_true",
                         help="Accept `scp:<file>` as the rspecifier and read its records natively by seeking (extension; "
                              "the reference refuses scp input, extract.py:59-61, because Kaldi binaries expand it upstream).")
@@ -273,7 +273,7 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
                 feats = dev.cpu().numpy()
             else:
                 with torch.cuda.device(dev_index):
-                    emb = trainer.predict_packed(dev, offsets).cpu().numpy()
+                    emb = trainer._checked(trainer.predict_packed(dev, offsets).cpu().numpy())
                 if normalize:
                     emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
                 writer.write(keys, emb)
@@ -291,7 +291,7 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
         host = torch.from_numpy(feats)                  # view of the pinned staging buffer
         with torch.cuda.device(dev_index):
             dev = host.to("cuda:%d" % dev_index, non_blocking=True)
-            emb = trainer.predict_packed(dev, offsets).cpu().numpy()
+            emb = trainer._checked(trainer.predict_packed(dev, offsets).cpu().numpy())
         if normalize:
             emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
         writer.write(keys, emb)

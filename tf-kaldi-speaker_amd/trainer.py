@@ -18,8 +18,10 @@ import numpy as np
 from . import _lib
 from . import model_io
 
-_PRECISIONS = {"f32": _lib.XV_PREC_F32, "bf16x3": _lib.XV_PREC_BF16X3}
-DEFAULT_PRECISION = "bf16x3"     # fast path: ~2e-6 rel-L2 on the x-vector (bar 1e-4); "f32" = exact fp32 MFMA
+_PRECISIONS = {"f32": _lib.XV_PREC_F32, "bf16x3": _lib.XV_PREC_BF16X3, "f16x3": _lib.XV_PREC_F16X3}
+# "bf16x3": split-precision MFMA over the full fp32 range, ~2e-6 rel-L2 on the x-vector (bar 1e-4);
+# "f16x3": the same kernels on fp16 hi/lo halves, ~3e-7, inputs / activations must stay within +-65504; "f32": exact fp32 MFMA
+DEFAULT_PRECISION = "bf16x3"
 
 
 def _relu_type(params):
@@ -343,6 +345,14 @@ class Trainer(object):
         _, info = self._plan(np.ascontiguousarray(offsets, dtype=np.int32), node or self.embeddings)
         return {f[0]: getattr(info, f[0]) for f in info._fields_}
 
+    def _checked(self, emb):
+        """f16x3 only: a feature or activation beyond the fp16 range (+-65504) overflows to inf and poisons the output.
+        Host copies of the results are checked so that this fails loudly instead of writing NaNs into an ark."""
+        if self._precision == "f16x3" and not np.isfinite(emb).all():
+            raise FloatingPointError("non-finite embedding from the f16x3 path: an input feature or activation exceeds the "
+                                     "fp16 range (+-65504); run with precision 'bf16x3' (full fp32 range) or 'f32'")
+        return emb
+
     def _lazy_load(self):
         # model/trainer.py:891-895
         if self.model is not None and os.path.isfile(os.path.join(self.model, "checkpoint")):
@@ -375,7 +385,7 @@ class Trainer(object):
             node = self.embeddings
             out = self.predict_packed(dev, offsets, node)
             _, info = self._plan(offsets, node)
-            emb = out.cpu().numpy()
+            emb = self._checked(out.cpu().numpy())
         if node == "attention_weights":
             emb = emb.reshape(b, -1, emb.shape[-1])
         elif info.frame_level and emb.shape[0] > b * t:       # ResNet block output [b, l, f, c] (test-only nodes)
@@ -413,7 +423,7 @@ class Trainer(object):
             dev = pin[:total].to("cuda:%d" % self._device_index, non_blocking=True)
             out = self.predict_packed(dev, offsets, node)
             _, info = self._plan(offsets, node)
-            emb = out.cpu().numpy()                     # synchronises: the staging buffer is free again
+            emb = self._checked(out.cpu().numpy())      # synchronises: the staging buffer is free again
         if node == "attention_weights" or not info.frame_level:
             return emb
         ctx = (int(offsets[-1]) - emb.shape[0]) // len(lens)
