@@ -141,9 +141,18 @@ int xv_finalize(xv_handle* h);
 /* Execution options, to be set before the plans they affect are created.  "pool_fusion" (default 1): statistics
  * pooling fused into the epilogue of the last frame-level layer; "tail_split" (default 1): deterministic K-split of
  * the last, nearly empty round of GEMM tiles.  Both change only the schedule (results agree to rounding); tests
- * switch them off to prove which path ran.  "profile_dominant" (default 0): xv_profile_* brackets only the step
+ * switch them off to prove which path ran.  "att_fusion" (default 1): attention scores / weighted moments computed in
+ * the epilogues of the last key layer / the value layer instead of from stored activations; "slab3" (default 1): one-tap
+ * layers on the kernel with three activation-slab buffers (0: the two-buffer kernel, bit-identical results).
+ * "profile_dominant" (default 0): xv_profile_* brackets only the step
  * with the most algorithmic FLOPs of each plan (two events per forward instead of two per kernel). */
 int xv_set_option(xv_handle* h, const char* name, int value);
+
+/* XV_PREC_F16X3 range guard.  Every kernel that converts a value to the fp16 split format records whether it was
+ * beyond +-65504 (or NaN).  Returns 1 if that happened in any xv_forward since the last reset (the results of those
+ * forwards are not valid: ReLU turns the NaNs that an overflow produces into zeros, so the outputs can look finite),
+ * 0 otherwise, or a negative status.  Synchronous device-to-host copy: call it after the results have been fetched. */
+int xv_check_overflow(xv_handle* h, int reset);
 
 /* endpoints[...] key -> node id (model/trainer.py:380 `endpoints[params.embedding_node]`).
  * Returns the id (>= 0) or XV_ERR_INVALID for a name the graph does not define. */

@@ -174,6 +174,35 @@ def test_fused_attention_path_matches_unfused_and_exact(kw):
         assert _rel(fused["tdnn6_dense"][i], ref) <= TOL, (i, kw)
 
 
+@pytest.mark.parametrize("net", ["tdnn_att", "resnet"])
+def test_three_slab_kernel_is_bit_identical_to_the_two_slab_kernel(net):
+    """One-tap layers (dense, attention epilogues, the ResNet grid convolutions) run on gemm_bf16x3_w1p3_kernel (three slab
+    buffers, slabs issued two steps ahead).  It performs the same MFMAs in the same order as the two-buffer kernel, so
+    every output must be bit-identical with xv_set_option "slab3" 0 -- a slab read before it has landed or overwritten
+    before it was read would show up here."""
+    from tf_kaldi_speaker_amd import synth
+    import torch
+    if net == "resnet":
+        params = dict(synth.RESNET_PARAMS)
+        weights = synth.synth_resnet_weights(params, seed=1)
+        dim, lens, nodes = 40, [120, 37, 64], ("tdnn6_dense", "conv3a", "conv5_relu")
+    else:
+        params = dict(synth.TDNN_ATT_PARAMS)
+        weights = synth.synth_weights(params, 30, seed=6)
+        dim, lens, nodes = 30, [300, 64, 200, 15, 129, 333, 78, 500] * 4, ("tdnn6_dense", "tdnn4_relu", "att_key1_relu")
+    utts = synth.synth_features(len(lens), lens, dim, seed=31)
+    feats = torch.from_numpy(np.concatenate(utts)).cuda()
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    for prec in ("bf16x3", "f16x3"):
+        tr = _trainer(params, weights, dim, prec)
+        a = _run_nodes(tr, feats, offs, nodes)
+        tr.set_option("slab3", 0)
+        b = _run_nodes(tr, feats, offs, nodes)
+        tr.close()
+        for node in nodes:
+            assert np.array_equal(a[node], b[node]), (net, prec, node)
+
+
 def test_f16x3_is_tighter_than_bf16x3_and_reports_overflow():
     """The fp16 hi/lo split format (XV_PREC_F16X3): same kernels and layout as bf16x3, 22 instead of 16 significand bits.
     At the BASELINE geometry its embeddings and its (peaky) attention weights must be several times closer to the exact

@@ -22,7 +22,7 @@ XV_POOL_STATISTICS = 0
 XV_POOL_SELF_ATTENTION = 1
 XV_ACT_RELU, XV_ACT_LRELU, XV_ACT_PRELU = 0, 1, 2
 
-EXPORTS = ["xv_version", "xv_create", "xv_set_tensor", "xv_finalize", "xv_set_option", "xv_node_id", "xv_node_context",
+EXPORTS = ["xv_version", "xv_create", "xv_set_tensor", "xv_finalize", "xv_set_option", "xv_check_overflow", "xv_node_id", "xv_node_context",
            "xv_plan_create", "xv_plan_query", "xv_plan_destroy", "xv_forward", "xv_profile_begin", "xv_profile_end",
            "xv_destroy", "xv_last_error",
            "xv_frontend_cmn_select", "xv_length_normalize", "xv_speaker_mean",
@@ -86,6 +86,7 @@ def load():
     lib.xv_set_tensor.argtypes = [vp, C.c_char_p, vp, C.POINTER(i64), i32]
     lib.xv_finalize.argtypes = [vp]
     lib.xv_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.xv_check_overflow.argtypes = [vp, i32]
     lib.xv_node_id.argtypes = [vp, C.c_char_p]
     lib.xv_node_context.argtypes = [vp, i32]
     lib.xv_plan_create.argtypes = [vp, vp, i32, i32, vp, C.POINTER(vp)]

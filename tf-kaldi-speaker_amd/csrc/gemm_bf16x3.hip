@@ -481,6 +481,146 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
   stamp(3);
 }
 
+// One-tap form (dense layers, and the ResNet grid convolutions whose taps are plain K blocks): every K step needs a new
+// activation slab.  With two slab buffers the slab of step s + 1 is issued at the top of step s and has to land within
+// that one step (the wait at the end of the step exposes whatever is left of its ~1 us LDS-DMA latency, every step):
+// measured 1.46-1.75 us per step against 1.36 us for the 7-tap convolution, whose slab has seven steps to land.  Here the
+// slabs rotate through THREE buffers (52 KB of LDS, still three workgroups per CU) and are issued TWO steps ahead, like
+// the weights; the wait at the end of step s only has to retire slab s + 1, issued a whole step earlier:
+//   VMEM order per step:  D x 4 (slab s+2, top) , a0 a1 a2 a3 (weights s+2)
+//   before group 0 / 4: vmcnt(15) as in w14p2 (same instruction counts per step); end of step: vmcnt(12)
+//   [younger than slab s+1: weights s+1 (4), slab s+2 (4), weights s+2 (4)], then the workgroup barrier (RAW for the slab
+//   read in step s+1; WAR for buffer (s+3) % 3 = s % 3, refilled at the top of step s+1).
+// The loop is unrolled by three, so the slab buffer of a step is a compile-time constant like its weight registers.
+template <int EPI, bool F16>
+__device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, char* smem3) {
+  char* As = smem3;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+
+  const int nsteps = p.Kpad >> 5;
+  const int lrow = lane >> 3, lpc = lane & 7;
+  const int64_t a_row_bytes = (p.a_pitch ? p.a_pitch : p.ldsbx) * 4;
+  const int kbt = p.a_pitch ? (p.ktap >> 5) : (p.Kpad >> 5);
+  const int64_t tap_bytes = p.a_pitch ? p.tap_stride * 4 : 0;
+  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(m0 + lrow) * a_row_bytes;
+  const int64_t nkb4k = (int64_t)(p.Kpad >> 5) * 4096;
+  const char* Wg = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((n0 >> 5) + wave) * nkb4k + lane * 16;
+  const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr_t)As;
+
+  auto dma_a = [&](int64_t koff, int buf, int g) {
+    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
+    const char* src = Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * DA_BYTES + g * 1024);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+  };
+  auto dma_slab = [&](int64_t koff, int buf) {      // the 16 eight-row groups of a slab: four per wave
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_a(koff, buf, i * 4 + wave);
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  auto stamp = [&](int i) {
+#ifdef XV_GEMM_TRACE
+    if (p.trace && tid == 0) p.trace[(int64_t)blockIdx.x * 8 + i] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  };
+  stamp(0);
+  // byte offset inside an A row of the K block of the slab to issue next (1-D form: block * 128; grid form: tap * tap_bytes
+  // + block-in-tap * 128), advanced incrementally
+  int64_t koff_issue = 0;
+  int blk_issue = 0;
+  auto advance = [&]() {
+    if (++blk_issue == kbt) {
+      blk_issue = 0;
+      koff_issue += tap_bytes - (int64_t)(kbt - 1) * 128;
+    } else {
+      koff_issue += 128;
+    }
+  };
+  bf16x8 W0[4], W1[4], W2[4];            // [plane * 2 + ks]; W0: step 0, W1: step 1
+  {
+    const char* q0 = Wg;
+    const char* q1 = Wg + (int64_t)(1 < nsteps ? 1 : 0) * 4096;
+    XV_GLD(W0[0], q0, 0); XV_GLD(W0[1], q0, 1024); XV_GLD(W0[2], q0, 2048); XV_GLD(W0[3], q0, 3072);
+    XV_GLD(W1[0], q1, 0); XV_GLD(W1[1], q1, 1024); XV_GLD(W1[2], q1, 2048); XV_GLD(W1[3], q1, 3072);
+  }
+  dma_slab(0, 0);                        // slab 0
+  advance();
+  dma_slab(1 < nsteps ? koff_issue : 0, 1);          // slab 1 (a duplicate of slab 0 when K is a single block)
+  advance();                             // koff_issue now describes slab 2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  stamp(1);
+  const int aswz = (r32 >> 1) & 7;
+  int off[4];                            // [ks * 2 + plane]: this lane's chunk of the swizzled 128-byte row
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    off[ks * 2] = ((ks * 2 + h) ^ aswz) << 4;
+    off[ks * 2 + 1] = ((4 + ks * 2 + h) ^ aswz) << 4;
+  }
+  auto step = [&](int s, int buf, bf16x8 (&Wc)[4], bf16x8 (&Wn)[4]) __attribute__((always_inline)) {
+    const char* q = Wg + (int64_t)(s + 2 < nsteps ? s + 2 : 0) * 4096;      // weights of step s + 2 (unconditional issue)
+    const char* ab = As + buf * DA_BYTES + r32 * DROW;
+    bf16x8 fh[8], fl[8];                 // activation fragments of group g = ks * 4 + mi, read two groups ahead
+    auto read_frag = [&](int g) {
+      const int ks = g >> 2, mi = g & 3;
+      fh[g] = *reinterpret_cast<const bf16x8*>(ab + off[ks * 2] + mi * (32 * DROW));
+      fl[g] = *reinterpret_cast<const bf16x8*>(ab + off[ks * 2 + 1] + mi * (32 * DROW));
+    };
+    read_frag(0);
+    read_frag(1);
+    dma_slab(s + 2 < nsteps ? koff_issue : 0, buf == 0 ? 2 : buf - 1);      // slab s + 2 into buffer (s + 2) % 3
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g == 0) XV_GLD(Wn[0], q, 0);        // hi ks0
+      if (g == 2) XV_GLD(Wn[2], q, 2048);     // lo ks0
+      if (g == 4) XV_GLD(Wn[1], q, 1024);     // hi ks1
+      if (g == 6) XV_GLD(Wn[3], q, 3072);     // lo ks1
+      if (g + 2 < 8) read_frag(g + 2);
+      if (g == 0) XV_WAIT2(15, Wc[0], Wc[2]);
+      if (g == 4) XV_WAIT2(15, Wc[1], Wc[3]);
+      const int ks = g >> 2, mi = g & 3;
+      const bf16x8 wh = Wc[ks], wl = Wc[2 + ks];
+      acc[mi] = mfma_split<F16>(wh, fl[g], acc[mi]);
+      acc[mi] = mfma_split<F16>(wl, fh[g], acc[mi]);
+      acc[mi] = mfma_split<F16>(wh, fh[g], acc[mi]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // slab s + 1 has landed (this wave's pieces)
+    __syncthreads();
+    advance();
+  };
+  for (int s = 0; s < nsteps; s += 3) {
+    step(s, 0, W0, W2);
+    if (s + 1 < nsteps) step(s + 1, 1, W1, W0);
+    if (s + 2 < nsteps) step(s + 2, 2, W2, W1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  stamp(2);
+  if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
+  else store_wave_tile_n32<64, F16>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
+  stamp(3);
+}
+
+template <int EPI = 0, bool F16 = false>
+__global__ __launch_bounds__(256, 3) void gemm_bf16x3_w1p3_kernel(GemmArgs p, int nMt, int nNt) {
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
+  const int mt = tile / nNt, nt = tile - mt * nNt;
+  w1p3_tile<EPI, F16>(p, mt * BM, nt * BN, smem3);
+}
+
 template <int NPS, int EPI = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_kernel(GemmArgs p, int nMt, int nNt, int w) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
@@ -524,19 +664,21 @@ __global__ void bf16x3_tail_reduce_kernel(GemmArgs p, int mt0, int S) {
     const int n = (int)(i - r * quads) * 4;
     const int64_t m = (int64_t)mt0 * BM + r;
     if (m >= p.M) continue;
-    const int orow = p.rowmap ? p.rowmap[m] : (int)m;
+    bool zero;
+    const int orow = out_row(p, (int)m, zero);
     if (orow < 0) continue;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < S; ++s) acc += *reinterpret_cast<const f32x4*>(p.partial + ((int64_t)s * rows + r) * p.Npad + n);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (n + e < p.N) v[e] = apply_act(fmaf(acc[e], p.scale[n + e], p.shift[n + e]), p.act, p.alpha ? p.alpha[n + e] : 0.f);
+      if (n + e < p.N && !zero) v[e] = apply_act(fmaf(acc[e], p.scale[n + e], p.shift[n + e]), p.act, p.alpha ? p.alpha[n + e] : 0.f);
     if (p.Y && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;     // N % 4 == 0 (wide epilogue)
     if (p.Ysb && n < p.ldsb) {
       uint32_t h01, l01, h23, l23;
       split2(v[0], v[1], h01, l01, p.f16);
       split2(v[2], v[3], h23, l23, p.f16);
+      if (p.f16) ovf_report(p.ovf, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
       char* blk = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128 + (n & 31) * 2;
       *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
       *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
@@ -599,6 +741,7 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
   static std::mutex init_mu;    // the attributes are per device; any thread may make the first launch on one
   static bool attr_set[64] = {};
   const size_t smemw32 = (size_t)2 * DA_BYTES;      // two slabs; the 4 x 8 KB epilogue scratch overlays them
+  const size_t smemw1p3 = (size_t)3 * DA_BYTES;     // one-tap form: three slabs (52 KB, three workgroups per CU)
 #ifdef XV_LAB
   static int force = 0;         // XVEC_GEMM_TILE (A/B): 128 register-staged | 1 LDS-DMA weights, barrier per step; 0 = default
   static int diag = 0;          // XVEC_GEMM_DIAG: timing-only ablation switches of the LDS-DMA kernel (outputs invalid)
@@ -620,6 +763,14 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
       hipError_t r = hipSuccess;
       for (const void* k : kernels) {
         r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
+        if (r != hipSuccess) return r;
+      }
+      const void* kernels3[] = {
+          reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, false>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, true>),
+          reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<1, false>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<1, true>),
+          reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<2, false>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<2, true>)};
+      for (const void* k : kernels3) {
+        r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw1p3);
         if (r != hipSuccess) return r;
       }
 #ifdef XV_LAB
@@ -657,12 +808,22 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
   if (a.att_part || a.pool_w) {                 // attention epilogue: dense layers without row compaction only
     if (w != 1 || a.rowmap || a.a_pitch || a.R || (a.N & 3) || (a.pool_w && !a.pool_part)) return hipErrorInvalidValue;
     const dim3 grid(nMt * nNt);
+    if (!a.slab3) {
+      if (a.att_part) {
+        if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 1, true>), grid, block, smemw32, s, a, nMt, nNt, w);
+        else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 1, false>), grid, block, smemw32, s, a, nMt, nNt, w);
+      } else {
+        if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 2, true>), grid, block, smemw32, s, a, nMt, nNt, w);
+        else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 2, false>), grid, block, smemw32, s, a, nMt, nNt, w);
+      }
+      return hipGetLastError();
+    }
     if (a.att_part) {
-      if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 1, true>), grid, block, smemw32, s, a, nMt, nNt, w);
-      else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 1, false>), grid, block, smemw32, s, a, nMt, nNt, w);
+      if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<1, true>), grid, block, smemw1p3, s, a, nMt, nNt);
+      else       hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<1, false>), grid, block, smemw1p3, s, a, nMt, nNt);
     } else {
-      if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 2, true>), grid, block, smemw32, s, a, nMt, nNt, w);
-      else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 2, false>), grid, block, smemw32, s, a, nMt, nNt, w);
+      if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<2, true>), grid, block, smemw1p3, s, a, nMt, nNt);
+      else       hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<2, false>), grid, block, smemw1p3, s, a, nMt, nNt);
     }
     return hipGetLastError();
   }
@@ -673,6 +834,11 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
 #ifdef XV_GEMM_TRACE
   if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
 #endif
+  if (w == 1 && !tail && a.slab3) {             // one tap: three slab buffers, slabs two steps ahead
+    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, true>), grid, block, smemw1p3, s, a, nMain, nNt);
+    else       hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, false>), grid, block, smemw1p3, s, a, nMain, nNt);
+    return hipGetLastError();
+  }
   if (w >= 5) {
     if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 0, true>), grid, block, smemw32, s, a, nMain, nNt, w);
     else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 0, false>), grid, block, smemw32, s, a, nMain, nNt, w);

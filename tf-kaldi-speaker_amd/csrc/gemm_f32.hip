@@ -158,11 +158,12 @@ __global__ void splitk_reduce_kernel(GemmArgs p) {
     const int m = (int)(i / p.N), n = (int)(i - (int64_t)m * p.N);
     float acc = 0.f;
     for (int s = 0; s < p.ksplit; ++s) acc += p.partial[((int64_t)s * p.M + m) * p.Npad + n];
-    const int orow = p.rowmap ? p.rowmap[m] : m;
+    bool zero;
+    const int orow = out_row(p, m, zero);
     if (orow < 0) continue;
     float v = fmaf(acc, p.scale[n], p.shift[n]);
     if (p.R) v += p.R[(int64_t)orow * p.ldr + n];          // residual shortcut before the activation
-    p.Y[(int64_t)orow * p.ldy + n] = apply_act(v, p.act, p.alpha ? p.alpha[n] : 0.f);
+    p.Y[(int64_t)orow * p.ldy + n] = zero ? 0.f : apply_act(v, p.act, p.alpha ? p.alpha[n] : 0.f);
   }
 }
 

@@ -1,10 +1,15 @@
 // Index and layout helpers for the ResNet-18 encoder (model/resnet.py:152-351).
 //
-// 2-D activations live on a zero-bordered NHWC "grid": utterance b owns (L_b + 2) x (F + 2) positions
-// of C channels starting at position (off0[b] + 2b) * (F + 2); the border stays zero, so TensorFlow's
-// 'same' padding of the 3x3 convolutions needs no bounds checks and every kernel row of a window is
-// one contiguous run of 3*C values -- the convolution becomes the overlapping-row GEMM of
-// xv_kernels.h (taps = kernel rows, tap stride = one padded time row).
+// 2-D activations live on a zero-bordered NHWC "grid": utterance b owns (L_b + 2) time rows of S positions
+// of C channels starting at position (off0[b] + 2b) * S; position 0 of a time row is the left border, positions
+// 1..F the frequency bins.  The pitch S is F + 1 -- the right border of a row IS the left border of the next row --
+// unless a consumer reads the value with a frequency stride of 2, which needs an even pitch: then S = F + 2.
+// The border stays zero, so TensorFlow's 'same' padding of the 3x3 convolutions needs no bounds checks and every
+// kernel row of a window is one contiguous run of 3*C values -- the convolution becomes the overlapping-row GEMM
+// of xv_kernels.h (taps = kernel rows, tap stride = one padded time row).  The GEMM rows of a layer enumerate the
+// positions of its INPUT (all of them, border included); rows that do not produce an output bin land on border
+// positions of the output, and their row-map entry says "write zeros there" (xv_epilogue.h out_row): the border
+// is re-zeroed by the epilogue, not by a memset of the whole value.
 #include "xv_epilogue.h"
 
 namespace xv {
@@ -21,7 +26,10 @@ __device__ __forceinline__ int find_utt(const int32_t* off0, int B, int64_t unit
   return lo;
 }
 
-__global__ void rowmap_grid_kernel(const int32_t* __restrict__ off0, int B, int rows_per_t, int Fout,
+// GEMM row m = (utterance b, padded time row t, j-th position of that row at the layer's frequency stride); output
+// position (t + 1, j + 1) of the output grid (pitch So): an output bin when t < L_b and j < Fout, else a border
+// position -- zeroed through this row when `cover` (the rows of a time row cover the whole output row: rows_per_t == So)
+__global__ void rowmap_grid_kernel(const int32_t* __restrict__ off0, int B, int rows_per_t, int Fout, int So, int cover,
                                    int32_t* __restrict__ rowmap, int64_t M) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
@@ -29,8 +37,8 @@ __global__ void rowmap_grid_kernel(const int32_t* __restrict__ off0, int B, int 
   const int64_t local = m - (int64_t)(off0[b] + 2 * b) * rows_per_t;
   const int t = (int)(local / rows_per_t), j = (int)(local - (int64_t)t * rows_per_t);
   const int L = off0[b + 1] - off0[b];
-  const int So = Fout + 2;
-  rowmap[m] = (t < L && j < Fout) ? (int32_t)((int64_t)(off0[b] + 2 * b) * So + (int64_t)(t + 1) * So + j + 1) : -1;
+  const int32_t pos = (int32_t)((int64_t)(off0[b] + 2 * b) * So + (int64_t)(t + 1) * So + j + 1);
+  rowmap[m] = (t < L && j < Fout) ? pos : (cover ? -pos - 2 : -1);
 }
 
 __global__ void rowmap_rows_kernel(const int32_t* __restrict__ off0, int B, int32_t* __restrict__ rowmap, int64_t M) {
@@ -42,24 +50,23 @@ __global__ void rowmap_rows_kernel(const int32_t* __restrict__ off0, int B, int3
   rowmap[m] = (t >= 1 && t <= L) ? off0[b] + t - 1 : -1;
 }
 
-__global__ void rowmap_interior_kernel(const int32_t* __restrict__ off0, int B, int F, int32_t* __restrict__ rowmap,
+// conv0: the GEMM rows ARE the output positions (pitch S); border positions are written as zeros
+__global__ void rowmap_interior_kernel(const int32_t* __restrict__ off0, int B, int F, int S, int32_t* __restrict__ rowmap,
                                        int64_t M) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= M) return;
-  const int S = F + 2;
   const int b = find_utt(off0, B, S, p);
   const int64_t local = p - (int64_t)(off0[b] + 2 * b) * S;
   const int t = (int)(local / S), f = (int)(local - (int64_t)t * S);
   const int L = off0[b + 1] - off0[b];
-  rowmap[p] = (t >= 1 && t <= L && f >= 1 && f <= F) ? (int32_t)p : -1;
+  rowmap[p] = (t >= 1 && t <= L && f >= 1 && f <= F) ? (int32_t)p : -(int32_t)p - 2;
 }
 
 // conv0 (3x3, cin = 1): one thread per (output grid position, pair of taps); taps 9..31 are zero padding
 template <bool SB>
 __global__ void im2col2d_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ off0, int B, int F,
-                                int64_t P, char* __restrict__ out, int f16) {
+                                int S, int64_t P, char* __restrict__ out, int f16, int* __restrict__ ovf) {
   const int64_t total = P * 16;
-  const int S = F + 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p = i >> 4;
     const int k = (int)(i & 15) * 2;
@@ -79,6 +86,7 @@ __global__ void im2col2d_kernel(const float* __restrict__ x, int64_t ldx, const 
     if (SB) {
       uint32_t hi, lo;
       split2(v[0], v[1], hi, lo, f16);
+      if (f16) ovf_report(ovf, fmaxf(fabsf(v[0]), fabsf(v[1])));
       char* blk = out + p * 128 + k * 2;
       *reinterpret_cast<uint32_t*>(blk) = hi;
       *reinterpret_cast<uint32_t*>(blk + 64) = lo;
@@ -90,9 +98,8 @@ __global__ void im2col2d_kernel(const float* __restrict__ x, int64_t ldx, const 
   }
 }
 
-__global__ void grid_unpad_kernel(const float* __restrict__ grid, const int32_t* __restrict__ off0, int B, int F, int C,
+__global__ void grid_unpad_kernel(const float* __restrict__ grid, const int32_t* __restrict__ off0, int B, int F, int S, int C,
                                   float* __restrict__ out, int64_t total) {
-  const int S = F + 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const int64_t pos = i / C;                 // dense position: frame * F + f
@@ -113,11 +120,11 @@ int launch_blocks(int64_t total) { return (int)((total + 255) / 256 > 8192 ? 819
 
 }  // namespace
 
-hipError_t launch_build_rowmap_grid(const int32_t* off0, int B, int rows_per_t, int Fout, int32_t* rowmap, int64_t M,
-                                    hipStream_t s) {
+hipError_t launch_build_rowmap_grid(const int32_t* off0, int B, int rows_per_t, int Fout, int So, int cover, int32_t* rowmap,
+                                    int64_t M, hipStream_t s) {
   if (M <= 0) return hipSuccess;
-  hipLaunchKernelGGL(rowmap_grid_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, off0, B, rows_per_t, Fout,
-                     rowmap, M);
+  hipLaunchKernelGGL(rowmap_grid_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, off0, B, rows_per_t, Fout, So,
+                     cover, rowmap, M);
   return hipGetLastError();
 }
 
@@ -127,33 +134,33 @@ hipError_t launch_build_rowmap_rows(const int32_t* off0, int B, int32_t* rowmap,
   return hipGetLastError();
 }
 
-hipError_t launch_build_rowmap_interior(const int32_t* off0, int B, int F, int32_t* rowmap, int64_t M, hipStream_t s) {
+hipError_t launch_build_rowmap_interior(const int32_t* off0, int B, int F, int S, int32_t* rowmap, int64_t M, hipStream_t s) {
   if (M <= 0) return hipSuccess;
-  hipLaunchKernelGGL(rowmap_interior_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, off0, B, F, rowmap, M);
+  hipLaunchKernelGGL(rowmap_interior_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, off0, B, F, S, rowmap, M);
   return hipGetLastError();
 }
 
-hipError_t launch_im2col2d_sb(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int64_t P, void* out_sb,
-                              int f16, hipStream_t s) {
+hipError_t launch_im2col2d_sb(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int S, int64_t P, void* out_sb,
+                              int f16, int* ovf, hipStream_t s) {
   if (P <= 0) return hipSuccess;
-  hipLaunchKernelGGL(im2col2d_kernel<true>, dim3(launch_blocks(P * 16)), dim3(256), 0, s, x, ldx, off0, B, F, P,
-                     static_cast<char*>(out_sb), f16);
+  hipLaunchKernelGGL(im2col2d_kernel<true>, dim3(launch_blocks(P * 16)), dim3(256), 0, s, x, ldx, off0, B, F, S, P,
+                     static_cast<char*>(out_sb), f16, ovf);
   return hipGetLastError();
 }
 
-hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int64_t P, float* out,
+hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int S, int64_t P, float* out,
                                hipStream_t s) {
   if (P <= 0) return hipSuccess;
-  hipLaunchKernelGGL(im2col2d_kernel<false>, dim3(launch_blocks(P * 16)), dim3(256), 0, s, x, ldx, off0, B, F, P,
-                     reinterpret_cast<char*>(out), 0);
+  hipLaunchKernelGGL(im2col2d_kernel<false>, dim3(launch_blocks(P * 16)), dim3(256), 0, s, x, ldx, off0, B, F, S, P,
+                     reinterpret_cast<char*>(out), 0, nullptr);
   return hipGetLastError();
 }
 
-hipError_t launch_grid_unpad_n(const float* grid, const int32_t* off0, int B, int F, int C, int64_t frames, float* out,
+hipError_t launch_grid_unpad_n(const float* grid, const int32_t* off0, int B, int F, int S, int C, int64_t frames, float* out,
                                hipStream_t s) {
   const int64_t total = frames * F * C;
   if (total <= 0) return hipSuccess;
-  hipLaunchKernelGGL(grid_unpad_kernel, dim3(launch_blocks(total)), dim3(256), 0, s, grid, off0, B, F, C, out, total);
+  hipLaunchKernelGGL(grid_unpad_kernel, dim3(launch_blocks(total)), dim3(256), 0, s, grid, off0, B, F, S, C, out, total);
   return hipGetLastError();
 }
 

@@ -403,7 +403,7 @@ hipError_t launch_att_weights_out(const float* scores, int H, const int32_t* off
 // One thread per (row, pair of k): the 30-dim input is tiny (36 KB/utterance), so materialising
 // the w*cin-wide rows once lets the first layer run on the bf16x3 MFMA kernel as a dense layer.
 __global__ void im2col_sb_kernel(const float* __restrict__ x, int64_t ldx, int cin, int K, int64_t rows,
-                                 char* __restrict__ out, int ldsb, int f16) {
+                                 char* __restrict__ out, int ldsb, int f16, int* __restrict__ ovf) {
   const int pairs = ldsb >> 1;
   const int64_t total = rows * pairs;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -418,6 +418,7 @@ __global__ void im2col_sb_kernel(const float* __restrict__ x, int64_t ldx, int c
     }
     uint32_t hi, lo;
     split2(v[0], v[1], hi, lo, f16);                 // hi/lo split in the format the GEMM consumes (xv_epilogue.h)
+    if (f16) ovf_report(ovf, fmaxf(fabsf(v[0]), fabsf(v[1])));      // a feature beyond the fp16 range
     char* blk = out + m * (int64_t)ldsb * 4 + (k >> 5) * 128 + (k & 31) * 2;
     *reinterpret_cast<uint32_t*>(blk) = hi;
     *reinterpret_cast<uint32_t*>(blk + 64) = lo;
@@ -425,12 +426,12 @@ __global__ void im2col_sb_kernel(const float* __restrict__ x, int64_t ldx, int c
 }
 
 hipError_t launch_im2col_sb(const float* x, int64_t ldx, int cin, int w, int64_t rows, void* out_sb, int ldsb, int f16,
-                            hipStream_t s) {
+                            int* ovf, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   const int64_t total = rows * (ldsb >> 1);
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(im2col_sb_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, cin, w * cin, rows,
-                     static_cast<char*>(out_sb), ldsb, f16);
+                     static_cast<char*>(out_sb), ldsb, f16, ovf);
   return hipGetLastError();
 }
 

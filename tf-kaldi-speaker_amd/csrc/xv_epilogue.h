@@ -61,6 +61,12 @@ __device__ __forceinline__ void split2t(float a, float b, uint32_t& hi, uint32_t
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - hf, bf16x2_t));
   }
 }
+// fp16 range guard: callers fold every value they convert into `m` (one v_max3_f32 per pair) and report once per wave
+constexpr float kF16Max = 65504.f;
+__device__ __forceinline__ void ovf_track(float& m, float a, float b) { m = fmaxf(m, fmaxf(fabsf(a), fabsf(b))); }
+__device__ __forceinline__ void ovf_report(int* flag, float m) {
+  if (flag && !(m <= kF16Max)) *flag = 1;              // also true for NaN; every reporter writes the same value
+}
 // run-time form for the kernels off the hot path (f16 is uniform over the launch)
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo, int f16) {
   if (f16) split2t<true>(a, b, hi, lo); else split2t<false>(a, b, hi, lo);
@@ -90,19 +96,30 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // A lane can therefore apply per-channel scale/shift with float4 loads, split to bf16 in packed
 // pairs and emit 8/16-byte LDS writes with no cross-lane traffic.
 
+// Output row of GEMM row m.  rowmap values: r >= 0 store at row r; -1 skip; r <= -2 store ZEROS at row -r - 2 (a border
+// position of a zero-bordered grid value that this GEMM row happens to cover: csrc/grid.hip -- this is what keeps the
+// border zero without a memset of the whole output per layer).
+__device__ __forceinline__ int out_row(const GemmArgs& p, int m, bool& zero) {
+  zero = false;
+  if (m >= p.M) return -1;
+  int r = p.rowmap ? p.rowmap[m] : m;
+  if (r < -1) { zero = true; r = -r - 2; }
+  return r;
+}
+
 // Scalar fallback (any N / alignment): one element at a time, fp32 and/or split-blocked.
 __device__ __forceinline__ void store_tile_scalar(const GemmArgs& p, const f32x16& acc, int mbase, int nbase, int lane) {
   const int r32 = lane & 31, h = lane >> 5;
   const int m = mbase + r32;
-  int orow = -1;
-  if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+  bool zero;
+  const int orow = out_row(p, m, zero);
   if (orow < 0) return;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int n = nbase + (e & 3) + 8 * (e >> 2) + 4 * h;
     const bool nok = n < p.N;
     float v = 0.f;
-    if (nok) {
+    if (nok && !zero) {
       v = p.raw ? acc[e] : fmaf(acc[e], p.scale[n], p.shift[n]);
       if (p.R) v += p.R[(int64_t)orow * p.ldr + n];
       v = apply_act(v, p.raw ? ACT_NONE : p.act, p.alpha ? p.alpha[n] : 0.f);
@@ -111,6 +128,7 @@ __device__ __forceinline__ void store_tile_scalar(const GemmArgs& p, const f32x1
     if (p.Ysb && n < p.ldsb) {
       uint32_t hi, lo;
       split2(v, 0.f, hi, lo, p.f16);
+      if (p.f16 && !(fabsf(v) <= kF16Max) && p.ovf) *p.ovf = 1;
       uint16_t* blk = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128);
       blk[n & 31] = (uint16_t)hi;
       blk[32 + (n & 31)] = (uint16_t)lo;
@@ -205,13 +223,17 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
         const int row = it * 4 + rrow;
         const int m = mbase + ps * ROWS + row;
         f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
-        int orow = -1;
-        if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+        bool zero;
+        const int orow = out_row(p, m, zero);
         if (orow < 0) continue;
         if (nok) {
-          v += *reinterpret_cast<const f32x4*>(p.R + (int64_t)orow * p.ldr + n);
+          if (zero) {
+            v = z;
+          } else {
+            v += *reinterpret_cast<const f32x4*>(p.R + (int64_t)orow * p.ldr + n);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], p.act, al4[i]);
+            for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], p.act, al4[i]);
+          }
           if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
         } else {
           v = z;
@@ -220,6 +242,7 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
           uint32_t h01, l01, h23, l23;
           split2(v[0], v[1], h01, l01, p.f16);
           split2(v[2], v[3], h23, l23, p.f16);
+          if (p.f16) ovf_report(p.ovf, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
           char* blk = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128 + (n & 31) * 2;
           *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
           *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
@@ -245,6 +268,7 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
             uint32_t h01, l01, h23, l23;
             split2(v[0], v[1], h01, l01, p.f16);
             split2(v[2], v[3], h23, l23, p.f16);
+            if (p.f16) ovf_report(p.ovf, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
             const int row = ml * 32 + r32;
             char* rp = scratch + row * 256 + 8 * h;
             *reinterpret_cast<uint2*>(rp + (((ni * 8 + q) ^ (row & 15)) << 4)) = make_uint2(h01, h23);
@@ -256,9 +280,10 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
       for (int it = 0; it < ROWS / 4; ++it) {
         const int row = it * 4 + rrow;
         const int m = mbase + ps * ROWS + row;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
-        int orow = -1;
-        if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
+        bool zero;
+        const int orow = out_row(p, m, zero);
+        if (zero) v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (orow >= 0 && blk_ok)
           *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (nbase >> 5) * 128 +
                                     rchunk * 16) = v;
@@ -277,9 +302,10 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
         for (int it = 0; it < ROWS / 4; ++it) {
           const int row = it * 4 + rrow;
           const int m = mbase + ps * ROWS + row;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
-          int orow = -1;
-          if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+          f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((rchunk ^ (row & 15)) << 4));
+          bool zero;
+          const int orow = out_row(p, m, zero);
+          if (zero) v = f32x4{0.f, 0.f, 0.f, 0.f};
           if (orow >= 0 && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
         }
       }
@@ -356,30 +382,32 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
   char* scratch = lds + wave * (ROWS * 128);
   const int rrow = lane >> 3, rchunk = lane & 7;        // read-back map: 8 frames x 8 chunks per pass
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  float vmax = 0.f;                                     // F16: largest magnitude converted by this lane (range guard)
 
-  f32x4 sc[4], sh[4], al[4];                            // this lane's channels 8q + 4h .. +3, q = 0..3
+  f32x4 sc[4], sh[4];                                   // this lane's channels 8q + 4h .. +3, q = 0..3
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int n4 = nbase + 8 * q + 4 * h;
     if (p.raw) {
       sc[q] = f32x4{1.f, 1.f, 1.f, 1.f};
       sh[q] = z;
-      al[q] = z;
     } else {
       const bool ok = n4 < p.N;
       sc[q] = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
       sh[q] = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
-      al[q] = (ok && p.alpha) ? *reinterpret_cast<const f32x4*>(p.alpha + n4) : z;
     }
   }
   XV_EPI_DRAIN();                                        // (trace builds: make the parameter-load latency visible)
   XV_EPI_STAMP(p, 4);
   auto value4 = [&](const f32x16& t, int q, bool pre_act) -> f32x4 {
+    f32x4 al = z;                                        // PReLU slopes: loaded at the point of use (registers are scarce)
+    if (ACT < 0 && !pre_act && p.alpha && !p.raw && nbase + 8 * q + 4 * h < p.N)
+      al = *reinterpret_cast<const f32x4*>(p.alpha + nbase + 8 * q + 4 * h);
     f32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float y = fmaf(t[4 * q + i], sc[q][i], sh[q][i]);
-      v[i] = pre_act ? y : apply_act(y, ACT < 0 ? p.act : ACT, al[q][i]);
+      v[i] = pre_act ? y : apply_act(y, ACT < 0 ? p.act : ACT, al[i]);
     }
     return v;
   };
@@ -406,13 +434,17 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
         const int row = it * 8 + rrow;
         const int m = mbase + ps * ROWS + row;
         f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
-        int orow = -1;
-        if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+        bool zero;
+        const int orow = out_row(p, m, zero);
         if (orow < 0) continue;
         if (nok) {
-          v += *reinterpret_cast<const f32x4*>(p.R + (int64_t)orow * p.ldr + n);
+          if (zero) {
+            v = z;
+          } else {
+            v += *reinterpret_cast<const f32x4*>(p.R + (int64_t)orow * p.ldr + n);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], p.act, al4[i]);
+            for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], p.act, al4[i]);
+          }
           if (p.Y) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
         } else {
           v = z;
@@ -421,6 +453,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
           uint32_t h01, l01, h23, l23;
           split2t<F16>(v[0], v[1], h01, l01);
           split2t<F16>(v[2], v[3], h23, l23);
+          if constexpr (F16) { ovf_track(vmax, v[0], v[1]); ovf_track(vmax, v[2], v[3]); }
           char* blk = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128 + (n & 31) * 2;
           *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
           *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
@@ -428,6 +461,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       }
       wave_lds_sync();
     }
+    if constexpr (F16) ovf_report(p.ovf, vmax);
     return;
   }
   if (p.Ysb) {
@@ -442,6 +476,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
           uint32_t h01, l01, h23, l23;
           split2t<F16>(v[0], v[1], h01, l01);
           split2t<F16>(v[2], v[3], h23, l23);
+          if constexpr (F16) { ovf_track(vmax, v[0], v[1]); ovf_track(vmax, v[2], v[3]); }
           const int row = ml * 32 + r32;
           char* rp = scratch + row * 128 + 8 * h;
           *reinterpret_cast<uint2*>(rp + ((q ^ (row & 7)) << 4)) = make_uint2(h01, h23);
@@ -453,9 +488,10 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       for (int it = 0; it < ROWS / 8; ++it) {
         const int row = it * 8 + rrow;
         const int m = mbase + ps * ROWS + row;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
-        int orow = -1;
-        if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
+        bool zero;
+        const int orow = out_row(p, m, zero);
+        if (zero) v = z;
         if (orow >= 0 && blk_ok)
           *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (nbase >> 5) * 128 +
                                     rchunk * 16) = v;
@@ -464,6 +500,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       wave_lds_sync();
     }
   }
+  if constexpr (F16) ovf_report(p.ovf, vmax);
   XV_EPI_STAMP(p, 5);
   if (p.Y || (ROWS == 64 && p.pool_part)) {
 #pragma unroll
@@ -476,9 +513,10 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
         for (int it = 0; it < ROWS / 8; ++it) {
           const int row = it * 8 + rrow;
           const int m = mbase + ps * ROWS + row;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
-          int orow = -1;
-          if (m < p.M) orow = p.rowmap ? p.rowmap[m] : m;
+          f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
+          bool zero;
+          const int orow = out_row(p, m, zero);
+          if (zero) v = z;
           if (orow >= 0 && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
         }
       }

@@ -41,6 +41,9 @@ struct GemmArgs {
   int ldsb;               // channels per SB output row incl. zero padding (multiple of 32)
   const void* Wsb;        // packed weights in SB format [Npad][Kpad/32][128 bytes]
   const void* Wfr = nullptr;   // weights, MFMA-fragment-major (gemm_bf16x3_wreg_kernel)
+  int slab3 = 1;               // one-tap layers: three slab buffers / slabs two steps ahead (gemm_bf16x3_w1p3_kernel); 0 = the
+                               // two-buffer kernel (same arithmetic, bit-identical results; xv_set_option "slab3")
+  int* ovf = nullptr;          // f16 only: set to 1 when a value beyond the fp16 range was converted (checked by the host)
   int f16 = 0;                 // split format of both operands: 0 = bf16 hi/lo (bf16x3), 1 = fp16 hi/lo (f16x3: same layout and
                                // MFMA rate, 11 + 11 significand bits instead of 8 + 8; values beyond +-65504 overflow)
   long long* trace = nullptr;  // debug: per-workgroup phase timestamps (XVEC_TRACE_K), 4 per workgroup
@@ -109,7 +112,7 @@ int64_t gemm_bf16x3_tail_plan(int M, int Kpad, int Npad, int w, int* tail_mt, in
 // fp32 frames -> split-blocked im2col rows for a small-cin first layer:
 //   out row m, k < w*cin: x[(m + k / cin) * ldx + k % cin]; zero padded to ldsb columns.
 hipError_t launch_im2col_sb(const float* x, int64_t ldx, int cin, int w, int64_t rows, void* out_sb, int ldsb, int f16,
-                            hipStream_t s);
+                            int* ovf, hipStream_t s);
 
 // bf16x3 split path (3x v_mfma_f32_32x32x16_bf16 per product tile).
 hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s);
@@ -131,23 +134,25 @@ hipError_t launch_build_row2utt(const int32_t* off0, int B, int ctx, int32_t* ro
 hipError_t launch_pool_finalize(const float* part, int C, const int32_t* off0, int B, int ctx,
                                 const int32_t* slotbase, float* out, int64_t ldo, hipStream_t s);
 
-// ---- ResNet grid helpers.  A "grid" value holds, per utterance b, (L_b + 2) x (F + 2) positions of C
-// channels with a zero border; utterance b starts at position (off0[b] + 2b) * (F + 2).
+// ---- ResNet grid helpers (csrc/grid.hip).  A "grid" value holds, per utterance b, (L_b + 2) time rows of S positions
+// of C channels with a zero border (S = F + 1, or F + 2 when a consumer reads it at frequency stride 2); utterance b
+// starts at position (off0[b] + 2b) * S.
 // rowmap of a conv whose GEMM rows enumerate (b, t', j): t' in [0, L_b + 2), j in [0, rows_per_t):
-//   valid iff t' < L_b and j < Fout;  out position (off0[b]+2b)*(Fout+2) + (t'+1)*(Fout+2) + j + 1
-hipError_t launch_build_rowmap_grid(const int32_t* off0, int B, int rows_per_t, int Fout, int32_t* rowmap, int64_t M,
-                                    hipStream_t s);
+//   output bin iff t' < L_b and j < Fout, at position (off0[b]+2b)*So + (t'+1)*So + j + 1; the other rows fall on border
+//   positions: encoded "write zeros" (-pos - 2) when cover (rows_per_t == So), else -1 (the caller zeroes the value)
+hipError_t launch_build_rowmap_grid(const int32_t* off0, int B, int rows_per_t, int Fout, int So, int cover, int32_t* rowmap,
+                                    int64_t M, hipStream_t s);
 // rowmap of conv5 (1 x F valid): rows enumerate padded time rows; valid iff 1 <= t' <= L_b -> frame off0[b]+t'-1
 hipError_t launch_build_rowmap_rows(const int32_t* off0, int B, int32_t* rowmap, int64_t M, hipStream_t s);
-// rowmap of conv0 (rows = grid positions): interior -> same position, border -> -1
-hipError_t launch_build_rowmap_interior(const int32_t* off0, int B, int F, int32_t* rowmap, int64_t M, hipStream_t s);
+// rowmap of conv0 (rows = grid positions, pitch S): interior -> same position, border -> zeros at the same position
+hipError_t launch_build_rowmap_interior(const int32_t* off0, int B, int F, int S, int32_t* rowmap, int64_t M, hipStream_t s);
 // conv0 im2col: out SB row p (grid position of the OUTPUT), k = kh*3+kw < 9: x[t+kh-1][f+kw-1] or 0
-hipError_t launch_im2col2d_sb(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int64_t P, void* out_sb,
-                              int f16, hipStream_t s);
-hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int64_t P, float* out,
+hipError_t launch_im2col2d_sb(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int S, int64_t P, void* out_sb,
+                              int f16, int* ovf, hipStream_t s);
+hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int S, int64_t P, float* out,
                                hipStream_t s);
 // grid [P, C] -> dense [sum L_b * F, C] (drops the zero border; test / endpoint output only)
-hipError_t launch_grid_unpad_n(const float* grid, const int32_t* off0, int B, int F, int C, int64_t frames, float* out,
+hipError_t launch_grid_unpad_n(const float* grid, const int32_t* off0, int B, int F, int S, int C, int64_t frames, float* out,
                                hipStream_t s);
 
 // sliding-window CMN + voiced-frame selection (csrc/frontend.hip); prefix: double [(frames + B) * dim] scratch

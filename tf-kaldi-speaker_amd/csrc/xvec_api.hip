@@ -105,7 +105,8 @@ enum OpKind : int {
 
 // A value is a matrix produced by an op (or the network input, value 0).
 struct Value {
-  int grid_F = 0;     // > 0: zero-bordered grid value with grid_F frequency bins (rows = (F0+2B)*(grid_F+2))
+  int grid_F = 0;     // > 0: zero-bordered grid value with grid_F frequency bins (rows = (F0+2B)*grid_S)
+  int grid_S = 0;     // its pitch: positions per padded time row (csrc/grid.hip: F + 1, or F + 2 under a stride-2 reader)
   bool frame_level = true;
   int ctx = 0;        // temporal context consumed (frame-level values): rows = F0 - B*ctx
   int cols = 0;
@@ -139,6 +140,7 @@ struct xv_handle {
   // options (xv_set_option)
   int opt_pool_fusion = 1;                            // statistics pooling fused into the last frame layer's epilogue
   int opt_tail_split = 1;                             // K-split of the last, nearly empty round of GEMM tiles
+  int opt_slab3 = 1;                                  // one-tap GEMM layers on the three-slab-buffer kernel
   int opt_att_fusion = 1;                             // attention scores / weighted moments in the GEMM epilogues
   int opt_profile_dominant = 0;                       // xv_profile_*: bracket only the step with the most FLOPs of a plan
   // device index arrays of destroyed plans, kept for the next plan (no hipMalloc / hipFree per ragged batch)
@@ -152,6 +154,7 @@ struct xv_handle {
   std::vector<Node> nodes;
   // attention extras
   DevBuf query;                 // [H, dk_h]
+  DevBuf ovf_flag;              // f16x3: one int, set by any kernel that converted a value beyond the fp16 range
   DevBuf query_eff;             // [H, Npad of the last key layer]: the query of head h over the padded key width, zero
                                 // outside the head's slice (fused score epilogue)
   int key_npad = 0;
@@ -184,6 +187,7 @@ struct PlanStep {
   int ksplit = 1;               // split-K slices of a small-M fp32 GEMM, or of the tail M tiles of a bf16x3 GEMM
   int tail_mt = 0;              // bf16x3: M tiles computed K-split (gemm_bf16x3_tail_plan)
   bool fuse_pool = false;       // GEMM: emit pooling partials instead of activations; STAT_POOL: finalize only
+  bool grid_cover = false;      // grid-valued output whose border is re-zeroed by zero-writing GEMM rows (no memset)
   int fuse_att = 0;             // GEMM: 1 = score partials instead of the key, 2 = weighted moments instead of the value;
                                 // ATT_SCORES / ATT_SOFTMAX / ATT_POOL: 1 = the fused form of that op
   int64_t att_w_off = -1;       // fuse_att 2: workspace offset of the softmax output (weights [rows, H])
@@ -470,6 +474,17 @@ int build_resnet(xv_handle* h) {
     const int last = (int)h->ops.size() - 1;
     add_node(h, "output", last, h->layers[h->ops[last].layer].final_stage());
   }
+  // Pitch of the grid values, one per stage (= per number of frequency bins, so that a layer's input, output and
+  // residual share it): F + 1 (shared border column) unless a value of the stage is read at frequency stride 2, which
+  // needs an even pitch -> F + 2.  With the default blocks: 42, 22, 12 for stages 1-3 and 6 for stage 4.
+  std::vector<int> wide;
+  for (const Op& op : h->ops) {
+    if (op.kind != OP_GEMM) continue;
+    const Layer& L = h->layers[op.layer];
+    if ((L.mode == 1 || L.mode == 2) && L.sw == 2 && op.in0 > 0) wide.push_back(h->values[op.in0].grid_F);
+  }
+  for (Value& v : h->values)
+    if (v.grid_F > 0) v.grid_S = v.grid_F + (std::find(wide.begin(), wide.end(), v.grid_F) != wide.end() ? 2 : 1);
   return XV_OK;
 }
 
@@ -687,7 +702,7 @@ int upload_layer(xv_handle* h, Layer& L) {
 
 int64_t value_rows(const xv_handle* h, int vid, int64_t F0, int B) {
   const Value& v = h->values[vid];
-  if (v.grid_F > 0) return (F0 + 2 * (int64_t)B) * (v.grid_F + 2);
+  if (v.grid_F > 0) return (F0 + 2 * (int64_t)B) * v.grid_S;
   return v.frame_level ? F0 - (int64_t)B * v.ctx : B;
 }
 
@@ -826,6 +841,8 @@ int xv_finalize(xv_handle* h) {
       XV_HIP(h, hipMemcpy(h->post_vec.p, vec.data(), vec.size() * sizeof(float), hipMemcpyHostToDevice));
     }
   }
+  XV_HIP(h, h->ovf_flag.alloc(sizeof(int)));
+  XV_HIP(h, hipMemset(h->ovf_flag.p, 0, sizeof(int)));
   XV_HIP(h, hipDeviceSynchronize());
   for (auto& kv : h->tensors) { kv.second.data.clear(); kv.second.data.shrink_to_fit(); }
   h->finalized = true;
@@ -838,9 +855,20 @@ int xv_set_option(xv_handle* h, const char* name, int value) {
   if (!strcmp(name, "pool_fusion")) h->opt_pool_fusion = value != 0;
   else if (!strcmp(name, "tail_split")) h->opt_tail_split = value != 0;
   else if (!strcmp(name, "att_fusion")) h->opt_att_fusion = value != 0;
+  else if (!strcmp(name, "slab3")) h->opt_slab3 = value != 0;
   else if (!strcmp(name, "profile_dominant")) h->opt_profile_dominant = value != 0;
   else return fail(h, XV_ERR_INVALID, "xv_set_option: unknown option '%s'", name);
   return XV_OK;
+}
+
+int xv_check_overflow(xv_handle* h, int reset) {
+  if (!h) return fail(nullptr, XV_ERR_INVALID, "xv_check_overflow: null handle");
+  if (!h->finalized || !h->ovf_flag.p) return 0;
+  DeviceGuard g(h->device);
+  int v = 0;
+  XV_HIP(h, hipMemcpy(&v, h->ovf_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (v && reset) XV_HIP(h, hipMemset(h->ovf_flag.p, 0, sizeof(int)));
+  return v ? 1 : 0;
 }
 
 int xv_node_id(const xv_handle* h, const char* name) {
@@ -1033,9 +1061,13 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       st.stage = st.to_out ? node.stage : L.final_stage();
       const int64_t padded_rows = F0 + 2 * (int64_t)batch;           // time rows incl. the two border rows per utterance
       if (L.mode == 0) st.M = (int)(st.rows_in - (L.w - 1));
-      else if (L.mode == 1 || L.mode == 2) st.M = (int)(padded_rows * ((L.Fin + 2) / L.sw));
+      else if (L.mode == 1 || L.mode == 2) st.M = (int)(padded_rows * (h->values[op.in0].grid_S / L.sw));
       else if (L.mode == 3) st.M = (int)padded_rows;
-      else st.M = (int)(padded_rows * (L.Fout + 2));                 // conv0: one row per output grid position
+      else st.M = (int)(padded_rows * h->values[op.out].grid_S);     // conv0: one row per output grid position
+      // does every border position of the output get a zero-writing GEMM row? (csrc/grid.hip)  If not the value is
+      // zeroed as a whole before the layer runs.
+      if (L.mode == 1 || L.mode == 2) st.grid_cover = h->values[op.in0].grid_S / L.sw == h->values[op.out].grid_S;
+      else if (L.mode == 4) st.grid_cover = true;
       if (L.w > 1 || L.mode != 0) {
         st.rowmap = (int)p->rowmap_off.size();
         p->rowmap_off.push_back(rowmap_elems);
@@ -1206,9 +1238,11 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       const int32_t* doff = static_cast<const int32_t*>(p->d_offsets.p);
       int32_t* rm = static_cast<int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.rowmap];
       if (L.mode == 0) e = launch_build_rowmap(doff, batch, ctx_in, L.w, rm, st.M, s);
-      else if (L.mode == 1 || L.mode == 2) e = launch_build_rowmap_grid(doff, batch, (L.Fin + 2) / L.sw, L.Fout, rm, st.M, s);
+      else if (L.mode == 1 || L.mode == 2)
+        e = launch_build_rowmap_grid(doff, batch, h->values[op.in0].grid_S / L.sw, L.Fout, h->values[op.out].grid_S,
+                                     st.grid_cover ? 1 : 0, rm, st.M, s);
       else if (L.mode == 3) e = launch_build_rowmap_rows(doff, batch, rm, st.M, s);
-      else e = launch_build_rowmap_interior(doff, batch, L.Fout, rm, st.M, s);
+      else e = launch_build_rowmap_interior(doff, batch, L.Fout, h->values[op.out].grid_S, rm, st.M, s);
       if (e != hipSuccess) return bail(e, "build_rowmap");
     }
   }
@@ -1332,13 +1366,22 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         a.Y = optr; a.ldy = L.cout;
         a.K = L.K();
         a.f16 = f16;
+        a.slab3 = h->opt_slab3;
+        a.ovf = static_cast<int*>(h->ovf_flag.p);
         const Value& vo = h->values[op.out];
-        if (vo.grid_F > 0) {              // zero the border (and everything else) of a grid output first
-          if (st.out_off >= 0) XV_HIP(h, hipMemsetAsync(ws + st.out_off, 0, (size_t)st.rows_out * L.cout * 4, s));
-          if (st.out_sb_off >= 0) XV_HIP(h, hipMemsetAsync(ws + st.out_sb_off, 0, (size_t)st.rows_out * sb_ld(L.cout) * 4, s));
+        if (vo.grid_F > 0) {
+          // the border of a grid output must be zero.  Covered outputs: the layer's own zero-writing rows do it, except
+          // for the first utterance's top border row and first left border (S + 1 positions no GEMM row maps to);
+          // otherwise the whole value is zeroed first.
+          const size_t head = (size_t)vo.grid_S + 1;
+          const size_t rows0 = st.grid_cover && L.mode != 4 ? head : (st.grid_cover ? 0 : (size_t)st.rows_out);
+          if (rows0 > 0) {
+            if (st.out_off >= 0) XV_HIP(h, hipMemsetAsync(ws + st.out_off, 0, rows0 * L.cout * 4, s));
+            if (st.out_sb_off >= 0) XV_HIP(h, hipMemsetAsync(ws + st.out_sb_off, 0, rows0 * sb_ld(L.cout) * 4, s));
+          }
         }
         if (L.mode == 1 || L.mode == 2 || L.mode == 3) {      // A addressing on the input grid (csrc/grid.hip)
-          const int64_t Sin = L.Fin + 2;
+          const int64_t Sin = h->values[op.in0].grid_S;
           a.a_pitch = (L.mode == 3 ? Sin : L.sw) * (int64_t)L.cin;
           a.a_off = L.mode == 1 ? (L.sw == 1 ? 0 : L.cin) : (L.mode == 2 ? (Sin + 1) * L.cin : L.cin);
           a.ntaps = L.mode == 1 ? 3 : 1;
@@ -1379,16 +1422,16 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           if (st.scratch_off < 0) return fail(h, XV_ERR_STATE, "conv0 has no scratch");
           a.cin = 32; a.K = 32;             // taps 9..31 are zero in both operands
           if (L.use_split) {
-            XV_HIP(h, launch_im2col2d_sb(feats, feat_ld, off, B, L.Fout, st.M, ws + st.scratch_off, f16, s));
+            XV_HIP(h, launch_im2col2d_sb(feats, feat_ld, off, B, L.Fout, vo.grid_S, st.M, ws + st.scratch_off, f16, static_cast<int*>(h->ovf_flag.p), s));
             a.Xsb = ws + st.scratch_off; a.ldsbx = 32; a.Wsb = L.wsb.p; a.Wfr = L.wfr.p;
             XV_HIP(h, launch_gemm_bf16x3(a, s));
           } else {
-            XV_HIP(h, launch_im2col2d_f32(feats, feat_ld, off, B, L.Fout, st.M, reinterpret_cast<float*>(ws + st.scratch_off), s));
+            XV_HIP(h, launch_im2col2d_f32(feats, feat_ld, off, B, L.Fout, vo.grid_S, st.M, reinterpret_cast<float*>(ws + st.scratch_off), s));
             a.X = reinterpret_cast<const float*>(ws + st.scratch_off); a.ldx = 32;
             XV_HIP(h, launch_gemm_f32(a, true, s));
           }
           if (st.unpad_to_out)
-            XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.cols,
+            XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.grid_S, vo.cols,
                                           p->info.in_frames, out, s));
           break;
         }
@@ -1396,7 +1439,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           // 30-dim first layer on the split kernel: materialise the w*cin-wide rows once (SB
           // format, K padded to 32), then it is a dense layer on those rows
           if (st.scratch_off < 0) return fail(h, XV_ERR_STATE, "im2col layer has no scratch");
-          XV_HIP(h, launch_im2col_sb(feats, feat_ld, L.cin, L.w, st.M, ws + st.scratch_off, L.Kpad, f16, s));
+          XV_HIP(h, launch_im2col_sb(feats, feat_ld, L.cin, L.w, st.M, ws + st.scratch_off, L.Kpad, f16, static_cast<int*>(h->ovf_flag.p), s));
           a.Xsb = ws + st.scratch_off;
           a.ldsbx = L.Kpad;
           a.cin = a.K;
@@ -1416,7 +1459,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           }
           XV_HIP(h, launch_gemm_bf16x3(a, s));
           if (st.unpad_to_out)
-            XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.cols,
+            XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.grid_S, vo.cols,
                                           p->info.in_frames, out, s));
           break;
         }
@@ -1429,7 +1472,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           return fail(h, XV_ERR_UNSUPPORTED, "resnet convolution %s needs channel counts that are multiples of 4", L.kernel_name.c_str());
         XV_HIP(h, launch_gemm_f32(a, aligned, s));
         if (st.unpad_to_out)
-          XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.cols,
+          XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.grid_S, vo.cols,
                                         p->info.in_frames, out, s));
         break;
       }
@@ -1608,6 +1651,7 @@ void xv_destroy(xv_handle* h) {
     DeviceGuard g(h->device);
     for (auto& L : h->layers) { L.wt.release(); L.wsb.release(); L.wfr.release(); L.vec.release(); }
     h->query.release();
+    h->ovf_flag.release();
     h->query_eff.release();
     h->post_vec.release();
     for (auto& b : h->pool) b.release();

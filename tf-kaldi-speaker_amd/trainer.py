@@ -345,12 +345,19 @@ class Trainer(object):
         _, info = self._plan(np.ascontiguousarray(offsets, dtype=np.int32), node or self.embeddings)
         return {f[0]: getattr(info, f[0]) for f in info._fields_}
 
+    def check_overflow(self):
+        """f16x3 only: True if a feature or activation went beyond the fp16 range (+-65504) in a forward since the
+        last check (xv_check_overflow; synchronous -- call after the results have been fetched)."""
+        if self._precision != "f16x3" or self._h is None:
+            return False
+        return _lib.check(self._lib.xv_check_overflow(self._h, 1), self._h) == 1
+
     def _checked(self, emb):
-        """f16x3 only: a feature or activation beyond the fp16 range (+-65504) overflows to inf and poisons the output.
-        Host copies of the results are checked so that this fails loudly instead of writing NaNs into an ark."""
-        if self._precision == "f16x3" and not np.isfinite(emb).all():
-            raise FloatingPointError("non-finite embedding from the f16x3 path: an input feature or activation exceeds the "
-                                     "fp16 range (+-65504); run with precision 'bf16x3' (full fp32 range) or 'f32'")
+        """Host copies of f16x3 results are range-checked, so that an overflow fails loudly instead of writing wrong
+        vectors into an ark (ReLU turns the NaNs an overflow produces into zeros: the output itself can look finite)."""
+        if self.check_overflow() or (self._precision == "f16x3" and not np.isfinite(emb).all()):
+            raise FloatingPointError("the f16x3 path converted a value beyond the fp16 range (+-65504): an input feature or an "
+                                     "activation is too large; run with precision 'bf16x3' (full fp32 range) or 'f32'")
         return emb
 
     def _lazy_load(self):
