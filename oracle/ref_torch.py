@@ -251,15 +251,17 @@ class TorchResnet18(object):
     @torch.no_grad()
     def forward(self, features):
         p, sc = self.params, self.scope
-        if _get(p, "resnet_time_stride", False) or _get(p, "resnet_maxpooling", False):
-            raise NotImplementedError("resnet_time_stride / resnet_maxpooling")
+        ts = 2 if _get(p, "resnet_time_stride", False) else 1                                # resnet.py:187
         blocks = list(_get(p, "resnet_blocks", [2, 2, 2, 2]))
         ep = OrderedDict()
         x = torch.as_tensor(np.ascontiguousarray(features)).to(self.dtype)[:, None]       # [b,1,l,40]
         x = self._act(self._bn(self._conv_same(x, "conv0_1"), "conv0_bn"), "conv0_relu")
         ep["conv0_relu"] = x.permute(0, 2, 3, 1)
+        if _get(p, "resnet_maxpooling", False):                                              # resnet.py:230-231
+            x = F.max_pool2d(x, 3, 1, padding=1)                                             # pads with -inf: 'same'
+            ep["conv0_max"] = x.permute(0, 2, 3, 1)
         for stage in (1, 2, 3, 4):
-            x = self._block(x, "conv%da" % stage, (1, 1) if stage == 1 else (1, 2), True, ep)
+            x = self._block(x, "conv%da" % stage, (1, 1) if stage == 1 else (ts, 2), True, ep)
             for i in range(blocks[stage - 1] - 1):
                 x = self._block(x, "conv%db_%d" % (stage, i), (1, 1), False, ep)
         k5 = self.w[sc + "/conv5/kernel"].permute(3, 2, 0, 1).contiguous()

@@ -153,13 +153,17 @@ def test_extended_tdnn_every_endpoint(precision, pooling):
     tr.close()
 
 
+@pytest.mark.parametrize("maxpool", [False, True])
 @pytest.mark.parametrize("width,precision", [(8, "f32"), (32, "f32"), (32, "bf16x3"), (32, "f16x3")])
-def test_resnet18_every_block(width, precision):
+def test_resnet18_every_block(width, precision, maxpool):
     """network_type "resnet_18" (model/resnet.py:152-351) block by block on a ragged batch; width 8 runs the
-    fp32 kernels with 24-wide taps, width 32 the split kernel on whole SB blocks."""
+    fp32 kernels with 24-wide taps, width 32 the split kernel on whole SB blocks.  With resnet_maxpooling (:230-231)
+    the 3x3 'same' max-pool behind conv0 is in the graph (endpoint conv0_max); the parametric ReLU makes activations
+    negative, so a max-pool that let the zero border take part would be caught."""
     import torch
     from tf_kaldi_speaker_amd import synth
-    params = dict(synth.RESNET_PARAMS, num_nodes_pooling_layer=96, network_relu_type="prelu", resnet_blocks=[2, 1, 2, 2])
+    params = dict(synth.RESNET_PARAMS, num_nodes_pooling_layer=96, network_relu_type="prelu", resnet_blocks=[2, 1, 2, 2],
+                  resnet_maxpooling=maxpool)
     weights = synth.synth_resnet_weights(params, seed=5, width=width)
     lens = [9, 14, 3]
     utts = synth.synth_features(len(lens), lens, 40, seed=15)
@@ -167,12 +171,13 @@ def test_resnet18_every_block(width, precision):
     packed = torch.from_numpy(np.concatenate(utts, axis=0)).cuda()
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     eps = [ref_numpy.entire_network(u[None], weights, params)[1] for u in utts]
+    assert ("conv0_max" in eps[0]) == maxpool
     for name in eps[0]:
         got = tr.predict_packed(packed, offsets, node=name).cpu().numpy()
         ref = np.concatenate([e[name].reshape(-1, e[name].shape[-1]) for e in eps], axis=0)
         assert got.shape == ref.shape, (name, got.shape, ref.shape)
         err = _rel(got, ref)
-        _note("resnet_w%d" % width, precision, name, err)
+        _note("resnet_w%d%s" % (width, "_max" if maxpool else ""), precision, name, err)
         assert err <= TOL, (name, err)
     tr.close()
 
@@ -238,6 +243,17 @@ def test_ragged_batch_matches_per_utterance(stat_model, precision):
         pos += n
     assert pos == frames.shape[0]
     tr.close()
+
+
+def test_resnet_time_stride_is_refused():
+    """resnet_time_stride (model/resnet.py:187) is the one graph option of the path that is not built: it must raise,
+    not be approximated."""
+    from tf_kaldi_speaker_amd import synth
+    from tf_kaldi_speaker_amd.params import Params
+    from tf_kaldi_speaker_amd.trainer import Trainer
+    tr = Trainer(Params(**dict(synth.RESNET_PARAMS, resnet_time_stride=True)), None, 40, single_cpu=True, device=0)
+    with pytest.raises(NotImplementedError):
+        tr.build("predict")
 
 
 def test_too_short_utterance_raises(stat_model):

@@ -116,7 +116,18 @@ def test_c_abi_library_exports_every_declared_symbol(repo_root):
         assert hasattr(lib, name), name
     lib.xv_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.xv_version()
-    assert ctypes.sizeof(_lib.ModelDesc) == 4 * (30 + 2 * (_lib.XV_MAX_ATT_LAYERS - 1))
+    # the ctypes mirrors have the size the C compiler gives the structs of the header
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "sz.c")
+        with open(src, "w") as f:
+            f.write('#include <stdio.h>\n#include "xvec_hip.h"\nint main(void) { printf("%zu %zu %zu\\n", sizeof(xv_model_desc), '
+                    'sizeof(xv_plan_info), sizeof(xv_kernel_time)); return 0; }\n')
+        exe = os.path.join(tmp, "sz")
+        subprocess.run(["gcc", "-I", os.path.join(repo_root, "include"), src, "-o", exe], check=True)
+        sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(_lib.ModelDesc), ctypes.sizeof(_lib.PlanInfo), ctypes.sizeof(_lib.KernelTime)]
 
 
 def test_trainer_refuses_unsupported_graphs_and_missing_gpu():

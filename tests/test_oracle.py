@@ -92,6 +92,8 @@ def test_extended_tdnn_restatements_agree(pooling):
 
 
 @pytest.mark.parametrize("kw", [{}, {"network_relu_type": "prelu", "resnet_blocks": [1, 2, 1, 3]},
+                                {"network_relu_type": "lrelu", "resnet_maxpooling": True},
+                                {"resnet_time_stride": True, "resnet_maxpooling": True},
                                 {"network_relu_type": "lrelu", "last_layer_linear": True}])
 def test_resnet18_restatements_agree(kw):
     """model/resnet.py:152-351: numpy tap-loop conv vs torch F.conv2d with explicit TF 'same' padding
@@ -101,8 +103,9 @@ def test_resnet18_restatements_agree(kw):
     feats = np.stack(synth.synth_features(2, 13, 40, seed=3))
     _, ep = ref_numpy.entire_network(feats, w, p)
     ep_t = ref_torch.TorchResnet18(w, p).forward(feats)
-    assert ep["conv2a"].shape == (2, 13, 20, 16) and ep["conv4a"].shape == (2, 13, 5, 64)      # 40 -> 20 -> 10 -> 5
-    assert ep["conv5_relu"].shape == (2, 13, 64) and ep["tdnn6_dense"].shape == (2, 64)
+    t2, t4 = (7, 2) if kw.get("resnet_time_stride") else (13, 13)                   # 'same', stride 2: 13 -> 7 -> 4 -> 2
+    assert ep["conv2a"].shape == (2, t2, 20, 16) and ep["conv4a"].shape == (2, t4, 5, 64)      # 40 -> 20 -> 10 -> 5
+    assert ep["conv5_relu"].shape == (2, t4, 64) and ep["tdnn6_dense"].shape == (2, 64)
     for k in ep:
         a, b = ep[k], ep_t[k].numpy().astype(np.float64)
         assert a.shape == b.shape, k

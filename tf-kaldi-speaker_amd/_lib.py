@@ -43,7 +43,7 @@ class ModelDesc(C.Structure):
         ("att_value_network_type", C.c_int32),
         ("att_apply_nonlinear", C.c_int32), ("att_use_scale", C.c_int32), ("att_num_heads", C.c_int32),
         ("att_split_value", C.c_int32), ("att_split_key", C.c_int32), ("precision", C.c_int32),
-        ("resnet_blocks", C.c_int32 * 4),
+        ("resnet_blocks", C.c_int32 * 4), ("resnet_maxpooling", C.c_int32), ("resnet_time_stride", C.c_int32),
     ]
 
 

@@ -98,6 +98,48 @@ __global__ void im2col2d_kernel(const float* __restrict__ x, int64_t ldx, const 
   }
 }
 
+// 3x3 stride-1 'same' max-pool on a grid value (model/resnet.py:230-231): one thread per (position, 4 channels).  An
+// interior position takes the maximum over its neighbours INSIDE the map (TensorFlow's 'same' max-pool ignores the
+// padding, so the zero border must not take part: leaky / parametric ReLU outputs can be negative); a border
+// position is written as zero, so the whole output grid is defined without a memset.  Reads fp32, writes fp32 and / or SB.
+__global__ void grid_maxpool3x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ off0, int B, int F, int S,
+                                       int C, int64_t P, float* __restrict__ y, char* __restrict__ ysb, int ldsb, int f16,
+                                       int* __restrict__ ovf) {
+  const int quads = C >> 2;
+  const int64_t total = P * quads;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / quads;
+    const int c = (int)(i - p * quads) * 4;
+    const int b = find_utt(off0, B, S, p);
+    const int64_t local = p - (int64_t)(off0[b] + 2 * b) * S;
+    const int t = (int)(local / S), f = (int)(local - (int64_t)t * S);
+    const int L = off0[b + 1] - off0[b];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t >= 1 && t <= L && f >= 1 && f <= F) {
+      v = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      for (int dt = -1; dt <= 1; ++dt) {
+        if (t + dt < 1 || t + dt > L) continue;
+        for (int df = -1; df <= 1; ++df) {
+          if (f + df < 1 || f + df > F) continue;
+          const f32x4 u = *reinterpret_cast<const f32x4*>(x + (p + (int64_t)dt * S + df) * C + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], u[e]);
+        }
+      }
+    }
+    if (y) *reinterpret_cast<f32x4*>(y + p * C + c) = v;
+    if (ysb) {
+      uint32_t h01, l01, h23, l23;
+      split2(v[0], v[1], h01, l01, f16);
+      split2(v[2], v[3], h23, l23, f16);
+      if (f16) ovf_report(ovf, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      char* blk = ysb + p * (int64_t)ldsb * 4 + (c >> 5) * 128 + (c & 31) * 2;
+      *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
+      *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
+    }
+  }
+}
+
 __global__ void grid_unpad_kernel(const float* __restrict__ grid, const int32_t* __restrict__ off0, int B, int F, int S, int C,
                                   float* __restrict__ out, int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -153,6 +195,15 @@ hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0,
   if (P <= 0) return hipSuccess;
   hipLaunchKernelGGL(im2col2d_kernel<false>, dim3(launch_blocks(P * 16)), dim3(256), 0, s, x, ldx, off0, B, F, S, P,
                      reinterpret_cast<char*>(out), 0, nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_grid_maxpool3x3(const float* x, const int32_t* off0, int B, int F, int S, int C, int64_t P, float* y,
+                                  void* ysb, int ldsb, int f16, int* ovf, hipStream_t s) {
+  if (P <= 0) return hipSuccess;
+  if (C & 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(grid_maxpool3x3_kernel, dim3(launch_blocks(P * (C >> 2))), dim3(256), 0, s, x, off0, B, F, S, C, P, y,
+                     static_cast<char*>(ysb), ldsb, f16, ovf);
   return hipGetLastError();
 }
 

@@ -151,6 +151,9 @@ hipError_t launch_im2col2d_sb(const float* x, int64_t ldx, const int32_t* off0, 
                               int f16, int* ovf, hipStream_t s);
 hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int S, int64_t P, float* out,
                                hipStream_t s);
+// 3x3 stride-1 'same' max-pool of a grid value [P, C] (fp32 in; fp32 and / or SB out, either may be null); borders -> 0
+hipError_t launch_grid_maxpool3x3(const float* x, const int32_t* off0, int B, int F, int S, int C, int64_t P, float* y,
+                                  void* ysb, int ldsb, int f16, int* ovf, hipStream_t s);
 // grid [P, C] -> dense [sum L_b * F, C] (drops the zero border; test / endpoint output only)
 hipError_t launch_grid_unpad_n(const float* grid, const int32_t* off0, int B, int F, int S, int C, int64_t frames, float* out,
                                hipStream_t s);

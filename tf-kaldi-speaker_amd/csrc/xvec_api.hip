@@ -100,7 +100,8 @@ enum OpKind : int {
   OP_ATT_SOFTMAX,     // in place on the scores buffer (modelled as its own value)
   OP_ATT_POOL,        // weighted mean/std
   OP_AFFINE_ACT,      // att_post_bn / att_post_relu
-  OP_L2_SCALE         // endpoints["output"] with feature_norm
+  OP_L2_SCALE,        // endpoints["output"] with feature_norm
+  OP_GRID_MAXPOOL     // 3x3 'same' max-pool on a grid value (resnet_maxpooling)
 };
 
 // A value is a matrix produced by an op (or the network input, value 0).
@@ -413,6 +414,7 @@ int build_resnet(xv_handle* h) {
   const int act = act_of(d);
   const std::string sc = "resnet_18/";
   if (d.feat_dim != 40) return fail(h, XV_ERR_INVALID, "resnet_18 needs 40-dim features (model/resnet.py:190)");
+  if (d.resnet_time_stride) return fail(h, XV_ERR_UNSUPPORTED, "resnet_time_stride is not implemented");
   if (d.pooling_type != XV_POOL_STATISTICS)
     return fail(h, XV_ERR_UNSUPPORTED, "resnet_18 registers no frame-level endpoints: only statistics_pooling is possible");
   h->values.clear();
@@ -420,6 +422,15 @@ int build_resnet(xv_handle* h) {
   h->values.push_back(in);
   int F = 40, cin = d.channels;
   int v = add_conv2d(h, sc + "conv0_1", sc + "conv0_bn", sc + "conv0_relu", 4, 1, cin, F, F, 1, act, 0, -1, "conv0_relu");
+  if (d.resnet_maxpooling) {                       // model/resnet.py:230-231
+    Value pv; pv.grid_F = F; pv.cols = cin;
+    const int vid = (int)h->values.size();
+    h->values.push_back(pv);
+    Op op; op.kind = OP_GRID_MAXPOOL; op.in0 = v; op.out = vid;
+    h->ops.push_back(op);
+    add_node(h, "conv0_max", (int)h->ops.size() - 1, -1);
+    v = vid;
+  }
   for (int stage = 1; stage <= 4; ++stage) {
     const int nf = d.channels << (stage - 1);
     const int sw = stage == 1 ? 1 : 2;
@@ -1298,6 +1309,7 @@ static const char* step_name(const xv_handle* h, const PlanStep& st) {
     case OP_ATT_POOL: return "att_pool";
     case OP_AFFINE_ACT: return "att_post";
     case OP_L2_SCALE: return "l2_scale";
+    case OP_GRID_MAXPOOL: return "conv0_max";
     default: return "op";
   }
 }
@@ -1527,6 +1539,16 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         const int a = st.stage >= 2 ? act_of(d) : ACT_NONE;
         XV_HIP(h, launch_affine_act(in_ptr(st.in0_off), n, B, n, vec, vec + n,
                                     (a == ACT_PRELU) ? vec + 2 * n : nullptr, a, optr, n, s));
+        break;
+      }
+      case OP_GRID_MAXPOOL: {
+        const Value& vo = h->values[op.out];
+        float* y = st.out_off >= 0 ? reinterpret_cast<float*>(ws + st.out_off) : nullptr;
+        XV_HIP(h, launch_grid_maxpool3x3(in_ptr(st.in0_off), off, B, vo.grid_F, vo.grid_S, vo.cols, st.rows_out, y,
+                                         st.out_sb_off >= 0 ? ws + st.out_sb_off : nullptr, sb_ld(vo.cols), f16,
+                                         static_cast<int*>(h->ovf_flag.p), s));
+        if (st.unpad_to_out)
+          XV_HIP(h, launch_grid_unpad_n(y, off, B, vo.grid_F, vo.grid_S, vo.cols, p->info.in_frames, out, s));
         break;
       }
       case OP_L2_SCALE: {

@@ -100,8 +100,8 @@ class Trainer(object):
         if p.network_type == "resnet_18":
             if self.dim != 40:
                 raise AssertionError("resnet_18 needs 40-dim features (model/resnet.py:190)")
-            if p.dict.get("resnet_time_stride", False) or p.dict.get("resnet_maxpooling", False):
-                raise NotImplementedError("resnet_time_stride / resnet_maxpooling are not built")
+            if p.dict.get("resnet_time_stride", False):
+                raise NotImplementedError("resnet_time_stride is not built (DESIGN.md section 7)")
             if "resnet_blocks" not in p.dict:
                 p.dict["resnet_blocks"] = [2, 2, 2, 2]                                  # model/resnet.py:203-204
             if p.pooling_type != "statistics_pooling":
@@ -135,6 +135,8 @@ class Trainer(object):
         d.precision = _PRECISIONS[self._precision]
         for i, n in enumerate(p.dict.get("resnet_blocks", [2, 2, 2, 2])):
             d.resnet_blocks[i] = int(n)
+        d.resnet_maxpooling = int(bool(p.dict.get("resnet_maxpooling", False)))
+        d.resnet_time_stride = int(bool(p.dict.get("resnet_time_stride", False)))
         if p.pooling_type == "self_attention":
             kn = list(p.att_key_num_nodes)
             vn = list(p.att_value_num_nodes)
