@@ -12,6 +12,12 @@ step att; python bench.py --pooling self_attention --cpu-seconds 0 --no-extra > 
 step varlen; python bench.py --varlen --cpu-seconds 0 --no-extra > $out/bench_varlen_bf16x3.json 2> $out/bench_varlen.err
 step etdnn; python bench.py --network extended_tdnn --cpu-seconds 0 --no-extra > $out/bench_etdnn_bf16x3.json 2> $out/bench_etdnn.err
 step resnet; python bench.py --network resnet_18 --batch 64 --dim 40 --cpu-seconds 4 --no-extra > $out/bench_resnet18_bf16x3.json 2> $out/bench_resnet.err
+step f16; python bench.py --precision f16x3 --cpu-seconds 0 --no-extra > $out/bench_f16x3.json 2> $out/bench_f16x3.err
+step att_f16; python bench.py --pooling self_attention --precision f16x3 --cpu-seconds 0 --no-extra > $out/bench_att_f16x3.json 2> $out/bench_att_f16.err
+step ab; for n in tdnn att resnet; do python tools/ab_options.py slab3 $n 2>&1 | grep -v amdgpu.ids; done > $out/ab_slab3.txt 2>&1
+python tools/ab_options.py att_fusion att 2>&1 | grep -v amdgpu.ids > $out/ab_att_fusion.txt 2>&1
+python tools/ab_options.py pool_fusion tdnn 2>&1 | grep -v amdgpu.ids > $out/ab_pool_fusion.txt 2>&1
+step cli; python tools/cli_throughput.py 100000 2>&1 | grep -v amdgpu.ids > $out/cli_throughput.txt; python tools/cli_throughput.py 300000 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt; python tools/cli_throughput.py 50000 --varlen 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt; python tools/cli_throughput.py 150000 --varlen 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt
 step trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --cpu-seconds 0 --no-extra > $out/trace.log 2>&1
 step pmc_sq; timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -- python bench.py --cpu-seconds 0 --no-extra --steps 3 --warmup 1 --no-profile > $out/pmc_sq.log 2>&1
 step pmc_fetch; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py --cpu-seconds 0 --no-extra --steps 3 --warmup 1 --no-profile > $out/pmc_fetch.log 2>&1
