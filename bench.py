@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--c4-steps", type=int, default=3, help="config 4: timed passes over the set")
     ap.add_argument("--c4-batch-frames", type=int, default=153600, help="config 4: frames per ragged device batch")
     ap.add_argument("--cli-utts", type=int, default=65536, help="cli leg: utterances in the ark")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the timing barrier (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses device 0 (with --dist-backend gloo)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the forward from a captured hipGraph (per-kernel events are then not recorded)")
     return ap.parse_args()
@@ -228,7 +231,7 @@ def config4_leg(tr, args, dist, world, rank, dev, weights, params):
     one_pass()                                         # warm-up: every geometry planned, every kernel loaded
     sync_dev()
     d = dist if world > 1 else None
-    elapsed = sharding.timed_steps(one_pass, args.c4_steps, sync_dev, dist=d, device=dev)
+    elapsed = sharding.timed_steps(one_pass, args.c4_steps, sync_dev, dist=d, device=dev if args.dist_backend == "nccl" else None)
     emb = torch.cat(outs, dim=0).cpu().numpy()
     order = np.array([i for b in batches for i in b], dtype=np.int64)
     full = sharding.gather_in_order(order, emb, len(lens), dist=d)
@@ -271,7 +274,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.one_device:
+            local_rank = 0
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print("[bench] note: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run for N>1" % (args.gpus, world),
@@ -310,6 +318,7 @@ def main():
 
     from tf_kaldi_speaker_amd import sharding
     d = dist if world > 1 else None
+    red_dev = dev if args.dist_backend == "nccl" else None     # where the max-over-ranks all_reduce lives
 
     def sync_dev():
         torch.cuda.synchronize(dev)
@@ -338,13 +347,13 @@ def main():
         tr.set_option("profile_dominant", 1)
         tr.profile_begin(max_events=2 * (args.steps + 1))
     # barrier + synchronize, exactly K steps, barrier + synchronize, max over ranks
-    elapsed = sharding.timed_steps(step, args.steps, sync_dev, dist=d, device=dev)
+    elapsed = sharding.timed_steps(step, args.steps, sync_dev, dist=d, device=red_dev)
     kernels, dominant = [], []
     if not args.no_profile:
         dominant, _ = tr.profile_end()
         tr.set_option("profile_dominant", 0)
         tr.profile_begin(max_events=2 * 48 * (args.steps + 1))
-        sharding.timed_steps(step, args.steps, sync_dev, dist=d, device=dev)
+        sharding.timed_steps(step, args.steps, sync_dev, dist=d, device=red_dev)
         kernels, _ = tr.profile_end()
     emb = out.cpu().numpy() if rank == 0 else None
     extra = not args.no_extra
@@ -352,13 +361,13 @@ def main():
     reps = []
     if extra and args.reps > 0:
         for _ in range(args.reps):
-            reps.append(sharding.timed_steps(step, args.steps, sync_dev, dist=d, device=dev))
+            reps.append(sharding.timed_steps(step, args.steps, sync_dev, dist=d, device=red_dev))
     graph_rate = None
     if extra and graph is None and not args.varlen:
         g2, _ = tr.capture_graph(feats, offsets, out=out)
         for _ in range(args.warmup):
             g2.replay()
-        el2 = sharding.timed_steps(g2.replay, args.steps, sync_dev, dist=d, device=dev)
+        el2 = sharding.timed_steps(g2.replay, args.steps, sync_dev, dist=d, device=red_dev)
         graph_rate = n_gpus * args.batch * args.steps / el2
         del g2
         tr.release_graphs()                                # the graph is gone: its plan / workspace may be reused
