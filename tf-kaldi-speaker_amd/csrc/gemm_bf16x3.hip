@@ -337,14 +337,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
 //    release as "+v" operands, so the compiler cannot move an MFMA above its wait.
 #define XV_GLD(dst, ptr, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(dst) : "v"(ptr))
 #define XV_WAIT2(N, ra, rb) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra), "+v"(rb) : "n"(N))
+#define XV_WAIT4(N, ra, rb, rc, rd) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra), "+v"(rb), "+v"(rc), "+v"(rd) : "n"(N))
 
 //  * the weight fragments are prefetched TWO steps ahead (three register buffers of 4 fragments).
 //    With one step of lead a workgroup alone on a CU is bound by the load->use latency (~0.9 us per step against
 // 0.4 us of MFMA work), so only three resident workgroups together cover the matrix pipe and every prologue,
 // epilogue and the tail of the launch leave it under-fed; with two steps of lead two workgroups suffice.
 //   VMEM order per step:  D x NPS (top) , a0 (group 0) a1 (group 2) a2 (group 4) a3 (group 6)   [for step s+2]
-//   step s+2: before group 0 wait vmcnt(7+2*NPS) [a0,a1 of s] ; before group 4 vmcnt(7+2*NPS) [a2,a3 of s] ;
-//   slab switch vmcnt(4).
+//   before the first MFMA of step s: vmcnt(5+2*NPS) [a0..a3 of step s, issued during step s-2: younger are the NPS slab
+//   pieces + 4 weight loads of step s-1 and the NPS pieces + a0 of step s]; slab switch vmcnt(4).
+//  * MFMA shape v_mfma_f32_16x16x32 (round 2): the wave tile is 8 x 2 accumulator tiles of 16 frames x 16 channels; per K
+//    step 48 MFMAs of 16 cycles instead of 24 of 32 -- the same operand bytes, LDS reads and FLOP per cycle, but the chip
+//    holds a clearly higher clock on this shape (a timing-only swap of the instruction inside this kernel: tdnn3_conv
+//    0.591 -> 0.500 ms; profiles/README.md).
 //  * K-split slices: the tile function takes the channel-block range [cb_begin, cb_end) so that the tail form
 //    (gemm_bf16x3_tail_plan) can run one slice of K per workgroup.
 // The activation fragment addresses use ONE swizzle and ONE row offset per lane ((32*mi + r) >> 1 == r >> 1 mod 8)
@@ -359,7 +364,7 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r32 = lane & 31, h = lane >> 5;
+  const int c16 = lane & 15, g4 = lane >> 4;       // 16x16x32 operand maps: row / column lane & 15, k chunk lane >> 4
 
   const int ncb = (p.Kpad >> 5) / w;
   const int nsteps = (cb_end - cb_begin) * w;      // channel blocks [cb_begin, cb_end): the whole K, or one K-split slice
@@ -380,11 +385,11 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
   };
 
-  f32x16 acc[4];
+  f32x4 acc[8][2];                       // [16-frame tile][16-channel tile]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int c = 0; c < 2; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // (cb, j) of the current step, of the next one and of the one after
   int cb = cb_begin, j = 0, cb1 = cb_begin, j1 = 1, cb2, j2;
@@ -398,7 +403,7 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
 #endif
   };
   stamp(0);
-  bf16x8 W0[4], W1[4], W2[4];            // [plane * 2 + ks]; W0: step 0, W1: step 1
+  bf16x8 W0[4], W1[4], W2[4];            // [plane * 2 + channel tile]; W0: step 0, W1: step 1
   {
     const char* q1 = Wg + (int64_t)(1 < nsteps ? j1 * ncb + cb1 : 0) * 4096;
     const char* q0 = Wg + (int64_t)cb_begin * 4096;               // step 0 = (cb_begin, tap 0)
@@ -416,19 +421,13 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
   auto step = [&](int s, bf16x8 (&Wc)[4], bf16x8 (&Wn)[4]) __attribute__((always_inline)) {
     const int kbn = s + 2 < nsteps ? j2 * ncb + cb2 : 0;        // weights of step s + 2 (unconditional issue)
     const char* q = Wg + (int64_t)kbn * 4096;
-    const char* ab = As + (cb & 1) * DA_BYTES + (r32 + j) * DROW;
-    const int aswz = ((r32 + j) >> 1) & 7;
-    int off[4];                          // [ks * 2 + plane]: this lane's chunk of the swizzled 128-byte row
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      off[ks * 2] = ((ks * 2 + h) ^ aswz) << 4;
-      off[ks * 2 + 1] = ((4 + ks * 2 + h) ^ aswz) << 4;
-    }
-    bf16x8 fh[8], fl[8];                 // activation fragments of group g = ks * 4 + mi, read two groups ahead
-    auto read_frag = [&](int g) {
-      const int ks = g >> 2, mi = g & 3;
-      fh[g] = *reinterpret_cast<const bf16x8*>(ab + off[ks * 2] + mi * (32 * DROW));
-      fl[g] = *reinterpret_cast<const bf16x8*>(ab + off[ks * 2 + 1] + mi * (32 * DROW));
+    const char* ab = As + (cb & 1) * DA_BYTES + (c16 + j) * DROW;
+    const int aswz = ((c16 + j) >> 1) & 7;           // (16 ft + r) >> 1 == r >> 1 (mod 8): one swizzle for all eight tiles
+    const int off_hi = (g4 ^ aswz) << 4, off_lo = ((4 + g4) ^ aswz) << 4;     // this lane's k chunk of the hi / lo half
+    bf16x8 fh[8], fl[8];                 // activation fragments of frame tile ft, read two tiles ahead
+    auto read_frag = [&](int ft) {
+      fh[ft] = *reinterpret_cast<const bf16x8*>(ab + off_hi + ft * (16 * DROW));
+      fl[ft] = *reinterpret_cast<const bf16x8*>(ab + off_lo + ft * (16 * DROW));
     };
     read_frag(0);
     read_frag(1);
@@ -439,19 +438,20 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (g == 0) XV_GLD(Wn[0], q, 0);        // hi ks0
-      if (g == 2) XV_GLD(Wn[2], q, 2048);     // lo ks0
-      if (g == 4) XV_GLD(Wn[1], q, 1024);     // hi ks1
-      if (g == 6) XV_GLD(Wn[3], q, 3072);     // lo ks1
+    for (int g = 0; g < 8; ++g) {        // g = frame tile: 6 MFMAs of 16 cycles
+      if (g == 0) XV_GLD(Wn[0], q, 0);        // hi, channels 0..15
+      if (g == 2) XV_GLD(Wn[1], q, 1024);     // hi, channels 16..31
+      if (g == 4) XV_GLD(Wn[2], q, 2048);     // lo, channels 0..15
+      if (g == 6) XV_GLD(Wn[3], q, 3072);     // lo, channels 16..31
       if (g + 2 < 8) read_frag(g + 2);
-      if (g == 0) XV_WAIT2(7 + 2 * NPS, Wc[0], Wc[2]);
-      if (g == 4) XV_WAIT2(7 + 2 * NPS, Wc[1], Wc[3]);
-      const int ks = g >> 2, mi = g & 3;
-      const bf16x8 wh = Wc[ks], wl = Wc[2 + ks];
-      acc[mi] = mfma_split<F16>(wh, fl[g], acc[mi]);
-      acc[mi] = mfma_split<F16>(wl, fh[g], acc[mi]);
-      acc[mi] = mfma_split<F16>(wh, fh[g], acc[mi]);
+      if (g == 0) XV_WAIT4(5 + 2 * NPS, Wc[0], Wc[1], Wc[2], Wc[3]);
+      // small cross terms first, the dominant hi*hi term last; the two channel tiles alternate
+      acc[g][0] = mfma_split16<F16>(Wc[0], fl[g], acc[g][0]);
+      acc[g][1] = mfma_split16<F16>(Wc[1], fl[g], acc[g][1]);
+      acc[g][0] = mfma_split16<F16>(Wc[2], fh[g], acc[g][0]);
+      acc[g][1] = mfma_split16<F16>(Wc[3], fh[g], acc[g][1]);
+      acc[g][0] = mfma_split16<F16>(Wc[0], fh[g], acc[g][0]);
+      acc[g][1] = mfma_split16<F16>(Wc[1], fh[g], acc[g][1]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (cb1 != cb) {                     // slab switch
@@ -476,8 +476,12 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   stamp(2);
-  if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
-  else store_wave_tile_n32<64, F16>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
+  // the epilogue's per-lane addresses all derive from the lane id: made opaque here, they cannot be hoisted above the K
+  // loop, where they would cost registers (and spill) for its whole duration
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
+  else store_wave_tile_n32<64, F16>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
   stamp(3);
 }
 
@@ -498,7 +502,7 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r32 = lane & 31, h = lane >> 5;
+  const int c16 = lane & 15, g4 = lane >> 4;       // 16x16x32 operand maps: row / column lane & 15, k chunk lane >> 4
 
   const int nsteps = p.Kpad >> 5;
   const int lrow = lane >> 3, lpc = lane & 7;
@@ -521,11 +525,11 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
     for (int i = 0; i < 4; ++i) dma_a(koff, buf, i * 4 + wave);
   };
 
-  f32x16 acc[4];
+  f32x4 acc[8][2];                       // [16-frame tile][16-channel tile]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int c = 0; c < 2; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto stamp = [&](int i) {
 #ifdef XV_GEMM_TRACE
@@ -545,7 +549,7 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
       koff_issue += 128;
     }
   };
-  bf16x8 W0[4], W1[4], W2[4];            // [plane * 2 + ks]; W0: step 0, W1: step 1
+  bf16x8 W0[4], W1[4], W2[4];            // [plane * 2 + channel tile]; W0: step 0, W1: step 1
   {
     const char* q0 = Wg;
     const char* q1 = Wg + (int64_t)(1 < nsteps ? 1 : 0) * 4096;
@@ -560,40 +564,34 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
   __syncthreads();
 
   stamp(1);
-  const int aswz = (r32 >> 1) & 7;
-  int off[4];                            // [ks * 2 + plane]: this lane's chunk of the swizzled 128-byte row
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    off[ks * 2] = ((ks * 2 + h) ^ aswz) << 4;
-    off[ks * 2 + 1] = ((4 + ks * 2 + h) ^ aswz) << 4;
-  }
+  const int aswz = (c16 >> 1) & 7;       // (16 ft + r) >> 1 == r >> 1 (mod 8): one swizzle for all eight tiles
+  const int off_hi = (g4 ^ aswz) << 4, off_lo = ((4 + g4) ^ aswz) << 4;       // this lane's k chunk of the hi / lo half
   auto step = [&](int s, int buf, bf16x8 (&Wc)[4], bf16x8 (&Wn)[4]) __attribute__((always_inline)) {
     const char* q = Wg + (int64_t)(s + 2 < nsteps ? s + 2 : 0) * 4096;      // weights of step s + 2 (unconditional issue)
-    const char* ab = As + buf * DA_BYTES + r32 * DROW;
-    bf16x8 fh[8], fl[8];                 // activation fragments of group g = ks * 4 + mi, read two groups ahead
-    auto read_frag = [&](int g) {
-      const int ks = g >> 2, mi = g & 3;
-      fh[g] = *reinterpret_cast<const bf16x8*>(ab + off[ks * 2] + mi * (32 * DROW));
-      fl[g] = *reinterpret_cast<const bf16x8*>(ab + off[ks * 2 + 1] + mi * (32 * DROW));
+    const char* ab = As + buf * DA_BYTES + c16 * DROW;
+    bf16x8 fh[8], fl[8];                 // activation fragments of frame tile ft, read two tiles ahead
+    auto read_frag = [&](int ft) {
+      fh[ft] = *reinterpret_cast<const bf16x8*>(ab + off_hi + ft * (16 * DROW));
+      fl[ft] = *reinterpret_cast<const bf16x8*>(ab + off_lo + ft * (16 * DROW));
     };
     read_frag(0);
     read_frag(1);
     dma_slab(s + 2 < nsteps ? koff_issue : 0, buf == 0 ? 2 : buf - 1);      // slab s + 2 into buffer (s + 2) % 3
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (g == 0) XV_GLD(Wn[0], q, 0);        // hi ks0
-      if (g == 2) XV_GLD(Wn[2], q, 2048);     // lo ks0
-      if (g == 4) XV_GLD(Wn[1], q, 1024);     // hi ks1
-      if (g == 6) XV_GLD(Wn[3], q, 3072);     // lo ks1
+    for (int g = 0; g < 8; ++g) {        // g = frame tile: 6 MFMAs of 16 cycles
+      if (g == 0) XV_GLD(Wn[0], q, 0);        // hi, channels 0..15
+      if (g == 2) XV_GLD(Wn[1], q, 1024);     // hi, channels 16..31
+      if (g == 4) XV_GLD(Wn[2], q, 2048);     // lo, channels 0..15
+      if (g == 6) XV_GLD(Wn[3], q, 3072);     // lo, channels 16..31
       if (g + 2 < 8) read_frag(g + 2);
-      if (g == 0) XV_WAIT2(15, Wc[0], Wc[2]);
-      if (g == 4) XV_WAIT2(15, Wc[1], Wc[3]);
-      const int ks = g >> 2, mi = g & 3;
-      const bf16x8 wh = Wc[ks], wl = Wc[2 + ks];
-      acc[mi] = mfma_split<F16>(wh, fl[g], acc[mi]);
-      acc[mi] = mfma_split<F16>(wl, fh[g], acc[mi]);
-      acc[mi] = mfma_split<F16>(wh, fh[g], acc[mi]);
+      if (g == 0) XV_WAIT4(13, Wc[0], Wc[1], Wc[2], Wc[3]);
+      acc[g][0] = mfma_split16<F16>(Wc[0], fl[g], acc[g][0]);
+      acc[g][1] = mfma_split16<F16>(Wc[1], fl[g], acc[g][1]);
+      acc[g][0] = mfma_split16<F16>(Wc[2], fh[g], acc[g][0]);
+      acc[g][1] = mfma_split16<F16>(Wc[3], fh[g], acc[g][1]);
+      acc[g][0] = mfma_split16<F16>(Wc[0], fh[g], acc[g][0]);
+      acc[g][1] = mfma_split16<F16>(Wc[1], fh[g], acc[g][1]);
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // slab s + 1 has landed (this wave's pieces)
@@ -608,8 +606,12 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   stamp(2);
-  if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
-  else store_wave_tile_n32<64, F16>(p, acc, m0, n0 + wave * 32, lane, wave, smem3);
+  // the epilogue's per-lane addresses all derive from the lane id: made opaque here, they cannot be hoisted above the K
+  // loop, where they would cost registers (and spill) for its whole duration
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
+  else store_wave_tile_n32<64, F16>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
   stamp(3);
 }
 

@@ -81,6 +81,16 @@ __device__ __forceinline__ f32x16 mfma_split(const bf16x8& a, const bf16x8& b, c
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// The product kernels use the 16x16x32 shape: same FLOP per cycle as 32x32x16, but the chip holds a visibly higher clock
+// on it under this load (MI355X_MICROARCH.md "DVFS give-back" item 7; measured in this kernel: profiles/README.md).
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_split16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // XCD-aware bijective remap of a 1-D grid (ids congruent mod 8 share an XCD and its L2).
 __device__ __forceinline__ int xcd_remap(int id, int n) {
   const int q = n >> 3, r = n & 7, x = id & 7, i = id >> 3;
@@ -117,6 +127,34 @@ __device__ __forceinline__ void store_tile_scalar(const GemmArgs& p, const f32x1
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int n = nbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+    const bool nok = n < p.N;
+    float v = 0.f;
+    if (nok && !zero) {
+      v = p.raw ? acc[e] : fmaf(acc[e], p.scale[n], p.shift[n]);
+      if (p.R) v += p.R[(int64_t)orow * p.ldr + n];
+      v = apply_act(v, p.raw ? ACT_NONE : p.act, p.alpha ? p.alpha[n] : 0.f);
+    }
+    if (p.Y && nok) p.Y[(int64_t)orow * p.ldy + n] = v;
+    if (p.Ysb && n < p.ldsb) {
+      uint32_t hi, lo;
+      split2(v, 0.f, hi, lo, p.f16);
+      if (p.f16 && !(fabsf(v) <= kF16Max) && p.ovf) *p.ovf = 1;
+      uint16_t* blk = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128);
+      blk[n & 31] = (uint16_t)hi;
+      blk[32 + (n & 31)] = (uint16_t)lo;
+    }
+  }
+}
+
+// The same for one 16x16 accumulator tile of the split kernels (lane & 15 -> frame, 4 * (lane >> 4) + i -> channel).
+__device__ __forceinline__ void store_tile16_scalar(const GemmArgs& p, const f32x4& acc, int mbase, int nbase, int lane) {
+  const int m = mbase + (lane & 15);
+  bool zero;
+  const int orow = out_row(p, m, zero);
+  if (orow < 0) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int n = nbase + 4 * (lane >> 4) + e;
     const bool nok = n < p.N;
     float v = 0.f;
     if (nok && !zero) {
@@ -368,56 +406,57 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
   }
 }
 
-// LDS-staged epilogue of a 128-frame x 32-channel wave tile acc[mi] (4 MFMA tiles stacked along M; the
-// "one wave per 32-channel block" layout of gemm_bf16x3_w14_kernel).  A row of the tile is exactly one SB block
+// LDS-staged epilogue of a 128-frame x 32-channel wave tile acc[ft][ct] (8 x 2 accumulator tiles of 16 frames x 16
+// channels, v_mfma_f32_16x16x32: lane & 15 -> frame, registers -> channels 4 * (lane >> 4) .. + 3; the "one wave per
+// 32-channel block" layout of the split kernels).  A row of the wave tile is exactly one SB block
 // (128 bytes) or 32 floats, so the scratch rows are 128 bytes (8 chunks, XOR-swizzled by frame & 7) and the
 // read-back hands 8 lanes one whole 128-byte line.  ROWS frames per pass (ROWS * 128 bytes of scratch per wave);
 // the fused statistics pooling needs ROWS == 64 (its partial slots are per 64-frame tile).
 template <int ACT, int ROWS, bool F16>
-__device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
+__device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, const f32x4 (&acc)[8][2], int mbase, int nbase,
                                                          int lane, int wave, char* lds) {
-  static_assert(ROWS == 32 || ROWS == 64 || ROWS == 128, "ROWS");
-  constexpr int NPASS = 128 / ROWS, MIP = ROWS / 32;
-  const int r32 = lane & 31, h = lane >> 5;
+  static_assert(ROWS == 64, "ROWS");
+  constexpr int NPASS = 128 / ROWS, FPP = ROWS / 16;     // passes, 16-frame accumulator tiles per pass
+  const int c16 = lane & 15, g4 = lane >> 4;
   char* scratch = lds + wave * (ROWS * 128);
   const int rrow = lane >> 3, rchunk = lane & 7;        // read-back map: 8 frames x 8 chunks per pass
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   float vmax = 0.f;                                     // F16: largest magnitude converted by this lane (range guard)
 
-  f32x4 sc[4], sh[4];                                   // this lane's channels 8q + 4h .. +3, q = 0..3
+  f32x4 sc[2], sh[2];                                   // this lane's channels 16 ct + 4 g4 .. +3, ct = 0, 1
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int n4 = nbase + 8 * q + 4 * h;
+  for (int ct = 0; ct < 2; ++ct) {
+    const int n4 = nbase + 16 * ct + 4 * g4;
     if (p.raw) {
-      sc[q] = f32x4{1.f, 1.f, 1.f, 1.f};
-      sh[q] = z;
+      sc[ct] = f32x4{1.f, 1.f, 1.f, 1.f};
+      sh[ct] = z;
     } else {
       const bool ok = n4 < p.N;
-      sc[q] = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
-      sh[q] = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
+      sc[ct] = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
+      sh[ct] = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
     }
   }
   XV_EPI_DRAIN();                                        // (trace builds: make the parameter-load latency visible)
   XV_EPI_STAMP(p, 4);
-  auto value4 = [&](const f32x16& t, int q, bool pre_act) -> f32x4 {
+  auto value4 = [&](const f32x4& t, int ct, bool pre_act) -> f32x4 {
     f32x4 al = z;                                        // PReLU slopes: loaded at the point of use (registers are scarce)
-    if (ACT < 0 && !pre_act && p.alpha && !p.raw && nbase + 8 * q + 4 * h < p.N)
-      al = *reinterpret_cast<const f32x4*>(p.alpha + nbase + 8 * q + 4 * h);
+    if (ACT < 0 && !pre_act && p.alpha && !p.raw && nbase + 16 * ct + 4 * g4 < p.N)
+      al = *reinterpret_cast<const f32x4*>(p.alpha + nbase + 16 * ct + 4 * g4);
     f32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float y = fmaf(t[4 * q + i], sc[q][i], sh[q][i]);
+      const float y = fmaf(t[i], sc[ct][i], sh[ct][i]);
       v[i] = pre_act ? y : apply_act(y, ACT < 0 ? p.act : ACT, al[i]);
     }
     return v;
   };
-  auto stage_f32 = [&](int ps, bool pre_act) {
+  auto stage_f32 = [&](int ps, bool pre_act) {          // fp32 chunk of channels 16 ct + 4 g4: index 4 ct + g4
 #pragma unroll
-    for (int ml = 0; ml < MIP; ++ml)
+    for (int fl = 0; fl < FPP; ++fl)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = ml * 32 + r32;
-        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((2 * q + h) ^ (row & 7)) << 4)) = value4(acc[ps * MIP + ml], q, pre_act);
+      for (int ct = 0; ct < 2; ++ct) {
+        const int row = fl * 16 + c16;
+        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ (row & 7)) << 4)) = value4(acc[ps * FPP + fl][ct], ct, pre_act);
       }
   };
   const int n = nbase + rchunk * 4;                      // read-back channels of this lane (fp32 forms)
@@ -429,7 +468,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
     for (int ps = 0; ps < NPASS; ++ps) {
       stage_f32(ps, true);
       wave_lds_sync();
-#pragma unroll 4
+#pragma unroll 2
       for (int it = 0; it < ROWS / 8; ++it) {
         const int row = it * 8 + rrow;
         const int m = mbase + ps * ROWS + row;
@@ -469,18 +508,21 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
-      for (int ml = 0; ml < MIP; ++ml)
+      for (int fl = 0; fl < FPP; ++fl)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 v = value4(acc[ps * MIP + ml], q, false);   // padding channels: scale = shift = 0 -> 0
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 v = value4(acc[ps * FPP + fl][ct], ct, false);   // padding channels: scale = shift = 0 -> 0
           uint32_t h01, l01, h23, l23;
           split2t<F16>(v[0], v[1], h01, l01);
           split2t<F16>(v[2], v[3], h23, l23);
           if constexpr (F16) { ovf_track(vmax, v[0], v[1]); ovf_track(vmax, v[2], v[3]); }
-          const int row = ml * 32 + r32;
-          char* rp = scratch + row * 128 + 8 * h;
-          *reinterpret_cast<uint2*>(rp + ((q ^ (row & 7)) << 4)) = make_uint2(h01, h23);
-          *reinterpret_cast<uint2*>(rp + (((4 + q) ^ (row & 7)) << 4)) = make_uint2(l01, l23);
+          // channels 16 ct + 4 g4 .. + 3: bytes 32 ct + 8 g4 of the hi half (chunk 2 ct + g4 / 2), the same of the lo half
+          const int row = fl * 16 + c16;
+          char* rp = scratch + row * 128 + 8 * (g4 & 1);
+          *reinterpret_cast<uint2*>(rp + (((2 * ct + (g4 >> 1)) ^ (row & 7)) << 4)) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(rp + (((4 + 2 * ct + (g4 >> 1)) ^ (row & 7)) << 4)) = make_uint2(l01, l23);
+          if constexpr (F16) __builtin_amdgcn_sched_barrier(0);   // one tile at a time: the fp16 conversions of eight
+                                                                  // interleaved tiles do not fit the register budget
         }
       wave_lds_sync();
       if (ps == 0) { XV_EPI_DRAIN(); XV_EPI_STAMP(p, 6); }
@@ -605,52 +647,53 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
 // Attention epilogue of the 128-frame x 32-channel wave tile (kernel instantiations with EPI = 1; dense layers only:
 // no rowmap).  Two forms, see GemmArgs:
 //  * att_part: the tile is the last key layer's output and only its dot products with the query are wanted
-//    (model/pooling.py:189-194).  A lane holds 16 channels of one frame per MFMA tile, so the partial score of
-//    (frame, head) is 16 FMAs in-lane plus one exchange between the two lane halves; the 32 frames of an MFMA tile
-//    are stored as one 128-byte run.  The 1500-wide key never leaves the registers.
+//    (model/pooling.py:189-194).  A lane holds 8 channels of one frame per 16-frame tile row, so the partial score of
+//    (frame, head) is 8 FMAs in-lane plus two exchanges across the four lane groups; the 16 frames of a tile
+//    are stored as one 64-byte run.  The 1500-wide key never leaves the registers.
 //  * pool_w: the tile is the value and only its weighted moments are wanted (:201-217): 64 frames are staged in the
 //    wave-private LDS scratch as in the statistics form, then per utterance segment and head s1 = sum w x and
 //    m2 = sum w (x - s1 / s0)^2 go to the segment's slot.
 template <int ACT, int FORM>
-__device__ __forceinline__ void store_wave_tile_n32_att_impl(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
+__device__ __forceinline__ void store_wave_tile_n32_att_impl(const GemmArgs& p, const f32x4 (&acc)[8][2], int mbase, int nbase,
                                                              int lane, int wave, char* lds) {
-  const int r32 = lane & 31, h = lane >> 5;
+  const int c16 = lane & 15, g4 = lane >> 4;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  f32x4 sc[4], sh[4];                                   // this lane's channels 8q + 4h .. +3, q = 0..3
+  f32x4 sc[2], sh[2];                                   // this lane's channels 16 ct + 4 g4 .. +3, ct = 0, 1
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int n4 = nbase + 8 * q + 4 * h;
+  for (int ct = 0; ct < 2; ++ct) {
+    const int n4 = nbase + 16 * ct + 4 * g4;
     const bool ok = n4 < p.N;
-    sc[q] = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
-    sh[q] = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
+    sc[ct] = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
+    sh[ct] = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
   }
-  auto value4 = [&](const f32x16& t, int q) -> f32x4 {
+  auto value4 = [&](const f32x4& t, int ct) -> f32x4 {
     f32x4 al = z;                                        // PReLU slopes: loaded at the point of use (registers are scarce)
-    if (ACT < 0 && p.alpha && nbase + 8 * q + 4 * h < p.N) al = *reinterpret_cast<const f32x4*>(p.alpha + nbase + 8 * q + 4 * h);
+    if (ACT < 0 && p.alpha && nbase + 16 * ct + 4 * g4 < p.N) al = *reinterpret_cast<const f32x4*>(p.alpha + nbase + 16 * ct + 4 * g4);
     f32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = apply_act(fmaf(t[4 * q + i], sc[q][i], sh[q][i]), ACT < 0 ? p.act : ACT, al[i]);
+    for (int i = 0; i < 4; ++i) v[i] = apply_act(fmaf(t[i], sc[ct][i], sh[ct][i]), ACT < 0 ? p.act : ACT, al[i]);
     return v;
   };
   if constexpr (FORM == 1) {
     const int blk = nbase >> 5;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      f32x4 v[4];                                        // this lane's 16 channels of frame mi * 32 + r32, activated
+    for (int ft = 0; ft < 8; ++ft) {
+      f32x4 v[2];                                        // this lane's 8 channels of frame ft * 16 + c16, activated
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = value4(acc[mi], q);   // padding channels: scale = shift = 0 and query 0
-      const int m = mbase + mi * 32 + r32;
+      for (int ct = 0; ct < 2; ++ct) v[ct] = value4(acc[ft][ct], ct);   // padding channels: scale = shift = 0 and query 0
+      const int m = mbase + ft * 16 + c16;
       for (int hd = 0; hd < p.att_heads; ++hd) {
-        const float* qp = p.att_q + (int64_t)hd * p.Npad + nbase + 4 * h;
+        const float* qp = p.att_q + (int64_t)hd * p.Npad + nbase + 4 * g4;
         float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + 8 * q);
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + 16 * ct);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) s = fmaf(v[q][i], qv[i], s);
+          for (int i = 0; i < 4; ++i) s = fmaf(v[ct][i], qv[i], s);
         }
-        s += __shfl_xor(s, 32, 64);                      // the other 16 channels of this frame
-        if (h == 0 && m < p.M) p.att_part[((int64_t)blk * p.att_heads + hd) * p.att_ld + m] = s;
+        s += __shfl_xor(s, 16, 64);                      // the other 24 channels of this frame (lane groups g4)
+        s += __shfl_xor(s, 32, 64);
+        if (g4 == 0 && m < p.M) p.att_part[((int64_t)blk * p.att_heads + hd) * p.att_ld + m] = s;
       }
     }
     return;
@@ -666,11 +709,11 @@ __device__ __forceinline__ void store_wave_tile_n32_att_impl(const GemmArgs& p, 
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
 #pragma unroll
-    for (int ml = 0; ml < 2; ++ml)
+    for (int fl = 0; fl < 4; ++fl)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = ml * 32 + r32;
-        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((2 * q + h) ^ (row & 7)) << 4)) = value4(acc[ps * 2 + ml], q);
+      for (int ct = 0; ct < 2; ++ct) {
+        const int row = fl * 16 + c16;
+        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ (row & 7)) << 4)) = value4(acc[ps * 4 + fl][ct], ct);
       }
     wave_lds_sync();
     const int mb = mbase + ps * 64;
@@ -762,7 +805,7 @@ __device__ __forceinline__ void store_wave_tile_n32_att_impl(const GemmArgs& p, 
 
 // FORM 1 = score partials (GemmArgs::att_part), 2 = weighted moments (GemmArgs::pool_w)
 template <int FORM>
-__device__ __forceinline__ void store_wave_tile_n32_att(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
+__device__ __forceinline__ void store_wave_tile_n32_att(const GemmArgs& p, const f32x4 (&acc)[8][2], int mbase, int nbase,
                                                         int lane, int wave, char* lds) {
   if (p.act == ACT_RELU)
     store_wave_tile_n32_att_impl<ACT_RELU, FORM>(p, acc, mbase, nbase, lane, wave, lds);
@@ -772,7 +815,7 @@ __device__ __forceinline__ void store_wave_tile_n32_att(const GemmArgs& p, const
 
 // Epilogue entry for the 128x32 wave tile.
 template <int ROWS, bool F16>
-__device__ __forceinline__ void store_wave_tile_n32(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
+__device__ __forceinline__ void store_wave_tile_n32(const GemmArgs& p, const f32x4 (&acc)[8][2], int mbase, int nbase,
                                                     int lane, int wave, char* lds);
 
 // true when the vectorised LDS-staged epilogue applies to this launch
@@ -803,7 +846,7 @@ __device__ __forceinline__ void store_wave_tile(const GemmArgs& p, const f32x16 
 }
 
 template <int ROWS, bool F16>
-__device__ __forceinline__ void store_wave_tile_n32(const GemmArgs& p, const f32x16 (&acc)[4], int mbase, int nbase,
+__device__ __forceinline__ void store_wave_tile_n32(const GemmArgs& p, const f32x4 (&acc)[8][2], int mbase, int nbase,
                                                     int lane, int wave, char* lds) {
   if (wide_epilogue_ok(p)) {
     if (p.act == ACT_RELU)
@@ -815,7 +858,9 @@ __device__ __forceinline__ void store_wave_tile_n32(const GemmArgs& p, const f32
     return;
   }
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) store_tile_scalar(p, acc[mi], mbase + mi * 32, nbase, lane);
+  for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) store_tile16_scalar(p, acc[ft][ct], mbase + ft * 16, nbase + ct * 16, lane);
 }
 
 }  // namespace xv

@@ -73,7 +73,7 @@ struct Layer {
   int act = ACT_NONE;         // activation of the final stage
   // device
   DevBuf wt;                  // fp32 [Npad][Kpad]                      (fp32 MFMA kernel)
-  DevBuf wfr;                 // same values, MFMA-fragment-major: [Npad/32][Kpad/32][plane*2+ks][64 lanes][16 B]
+  DevBuf wfr;                 // same values, MFMA-fragment-major: [Npad/32][Kpad/32][plane*2+channel tile][64 lanes][16 B]
   DevBuf wsb;                 // split-blocked bf16 hi/lo [Npad][Kpad/32][128 B] (bf16x3 kernel)
   bool use_split = false;     // this layer runs on the bf16x3 kernel
   bool im2col = false;        // first layer in bf16x3 mode: fp32 frames -> SB im2col rows -> dense split GEMM
@@ -694,15 +694,17 @@ int upload_layer(xv_handle* h, Layer& L) {
     }
     XV_HIP(h, L.wsb.alloc(elems * 4));
     XV_HIP(h, hipMemcpy(L.wsb.p, sb.data(), elems * 4, hipMemcpyHostToDevice));
-    // fragment-major copy for the weights-in-registers kernel: one global_load_dwordx4 of a wave = 1 KB contiguous
+    // fragment-major copy for the weights-in-registers kernels (v_mfma_f32_16x16x32 A operand: lane = 16 * k-chunk + row):
+    // per (32-channel block, K block) 4 KB = [plane hi/lo][16-channel tile][64 lanes][16 B]; one global_load_dwordx4 of a
+    // wave = 1 KB contiguous
     std::vector<uint16_t> fr(elems * 2, 0);
     const size_t nkb = L.Kpad / 32;
     for (size_t n = 0; n < (size_t)L.Npad; ++n)
       for (size_t kb = 0; kb < nkb; ++kb)
-        for (int q = 0; q < 8; ++q) {                       // SB chunk q = plane*4 + ks*2 + half
-          const int plane = q >> 2, ks = (q >> 1) & 1, hh = q & 1;
+        for (int q = 0; q < 8; ++q) {                       // SB chunk q = plane * 4 + k-chunk (8 k values, 16 bytes)
+          const int plane = q >> 2, g = q & 3, ct = (int)((n >> 4) & 1);
           const size_t src = (n * nkb + kb) * 64 + (size_t)q * 8;
-          const size_t dst = ((((n / 32) * nkb + kb) * 4 + plane * 2 + ks) * 64 + hh * 32 + (n & 31)) * 8;
+          const size_t dst = ((((n / 32) * nkb + kb) * 4 + plane * 2 + ct) * 64 + g * 16 + (n & 15)) * 8;
           for (int e = 0; e < 8; ++e) fr[dst + e] = sb[src + e];
         }
     XV_HIP(h, L.wfr.alloc(elems * 4));
