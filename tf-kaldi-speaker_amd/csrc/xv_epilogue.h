@@ -67,6 +67,12 @@ __device__ __forceinline__ void ovf_track(float& m, float a, float b) { m = fmax
 __device__ __forceinline__ void ovf_report(int* flag, float m) {
   if (flag && !(m <= kF16Max)) *flag = 1;              // also true for NaN; every reporter writes the same value
 }
+// the same guard on the converted halves (hot epilogue: integer ops on registers that exist anyway, no extra live floats):
+// a half is inf / NaN iff its exponent field is all ones, i.e. adding 1 to the field carries into the sign bit
+__device__ __forceinline__ void ovf_bits(uint32_t& bad, uint32_t hi) { bad |= (hi & 0x7C007C00u) + 0x04000400u; }
+__device__ __forceinline__ void ovf_report_bits(int* flag, uint32_t bad) {
+  if (flag && (bad & 0x80008000u)) *flag = 1;
+}
 // run-time form for the kernels off the hot path (f16 is uniform over the launch)
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo, int f16) {
   if (f16) split2t<true>(a, b, hi, lo); else split2t<false>(a, b, hi, lo);
@@ -178,9 +184,11 @@ __device__ __forceinline__ void store_tile16_scalar(const GemmArgs& p, const f32
 // wave and DS instructions of one wave execute in order, so no workgroup barrier (and no s_barrier at all) is
 // needed -- only that the compiler keeps the program order.
 __device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // No fence builtin here: on gfx950 vmcnt counts loads AND stores, and a release / acquire pair makes the compiler
+  // drain it -- the wave would sit until the global stores of the previous pass are acknowledged (microseconds under
+  // load) before it may restage the scratch.  Only compiler order (the asm memory clobber) and LDS order are needed.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // LDS-staged epilogue of a 64x64 wave tile acc[ni][mi] (2x2 MFMA tiles, orientation above).
@@ -421,7 +429,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
   char* scratch = lds + wave * (ROWS * 128);
   const int rrow = lane >> 3, rchunk = lane & 7;        // read-back map: 8 frames x 8 chunks per pass
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  float vmax = 0.f;                                     // F16: largest magnitude converted by this lane (range guard)
+  uint32_t bad = 0;                                     // F16 range guard: exponent-overflow bits of the converted hi halves
 
   f32x4 sc[2], sh[2];                                   // this lane's channels 16 ct + 4 g4 .. +3, ct = 0, 1
 #pragma unroll
@@ -436,6 +444,22 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       sh[ct] = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
     }
   }
+  // Row map entries of every row this lane will store (8 per pass), loaded BEFORE the first store: vmcnt counts loads and
+  // stores together and in order, so a row-map load issued behind the stores of the previous pass could only be consumed
+  // once those stores are acknowledged (the convolutions' epilogue spent most of its time there).
+  int rmap[NPASS][ROWS / 8];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+    for (int it = 0; it < ROWS / 8; ++it) {
+      const int m = mbase + ps * ROWS + it * 8 + rrow;
+      rmap[ps][it] = m < p.M ? (p.rowmap ? p.rowmap[m] : m) : -1;
+    }
+  auto out_row_pre = [&](int ps, int it, bool& zero) -> int {      // out_row() on the preloaded entry
+    int r = rmap[ps][it];
+    zero = r < -1;
+    return zero ? -r - 2 : r;
+  };
   XV_EPI_DRAIN();                                        // (trace builds: make the parameter-load latency visible)
   XV_EPI_STAMP(p, 4);
   auto value4 = [&](const f32x4& t, int ct, bool pre_act) -> f32x4 {
@@ -474,7 +498,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
         const int m = mbase + ps * ROWS + row;
         f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
         bool zero;
-        const int orow = out_row(p, m, zero);
+        const int orow = out_row_pre(ps, it, zero);
         if (orow < 0) continue;
         if (nok) {
           if (zero) {
@@ -492,7 +516,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
           uint32_t h01, l01, h23, l23;
           split2t<F16>(v[0], v[1], h01, l01);
           split2t<F16>(v[2], v[3], h23, l23);
-          if constexpr (F16) { ovf_track(vmax, v[0], v[1]); ovf_track(vmax, v[2], v[3]); }
+          if constexpr (F16) { ovf_bits(bad, h01); ovf_bits(bad, h23); }
           char* blk = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128 + (n & 31) * 2;
           *reinterpret_cast<uint2*>(blk) = make_uint2(h01, h23);
           *reinterpret_cast<uint2*>(blk + 64) = make_uint2(l01, l23);
@@ -500,7 +524,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       }
       wave_lds_sync();
     }
-    if constexpr (F16) ovf_report(p.ovf, vmax);
+    if constexpr (F16) ovf_report_bits(p.ovf, bad);
     return;
   }
   if (p.Ysb) {
@@ -515,9 +539,11 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
           uint32_t h01, l01, h23, l23;
           split2t<F16>(v[0], v[1], h01, l01);
           split2t<F16>(v[2], v[3], h23, l23);
-          if constexpr (F16) { ovf_track(vmax, v[0], v[1]); ovf_track(vmax, v[2], v[3]); }
           // channels 16 ct + 4 g4 .. + 3: bytes 32 ct + 8 g4 of the hi half (chunk 2 ct + g4 / 2), the same of the lo half
           const int row = fl * 16 + c16;
+          if constexpr (F16) {                           // rows past M hold whatever the slack behind the input held
+            if (mbase + ps * ROWS + row < p.M) { ovf_bits(bad, h01); ovf_bits(bad, h23); }
+          }
           char* rp = scratch + row * 128 + 8 * (g4 & 1);
           *reinterpret_cast<uint2*>(rp + (((2 * ct + (g4 >> 1)) ^ (row & 7)) << 4)) = make_uint2(h01, h23);
           *reinterpret_cast<uint2*>(rp + (((4 + 2 * ct + (g4 >> 1)) ^ (row & 7)) << 4)) = make_uint2(l01, l23);
@@ -532,7 +558,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
         const int m = mbase + ps * ROWS + row;
         f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
         bool zero;
-        const int orow = out_row(p, m, zero);
+        const int orow = out_row_pre(ps, it, zero);
         if (zero) v = z;
         if (orow >= 0 && blk_ok)
           *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (nbase >> 5) * 128 +
@@ -542,7 +568,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       wave_lds_sync();
     }
   }
-  if constexpr (F16) ovf_report(p.ovf, vmax);
+  if constexpr (F16) ovf_report_bits(p.ovf, bad);
   XV_EPI_STAMP(p, 5);
   if (p.Y || (ROWS == 64 && p.pool_part)) {
 #pragma unroll
@@ -557,7 +583,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
           const int m = mbase + ps * ROWS + row;
           f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
           bool zero;
-          const int orow = out_row(p, m, zero);
+          const int orow = out_row_pre(ps, it, zero);
           if (zero) v = z;
           if (orow >= 0 && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;
         }
