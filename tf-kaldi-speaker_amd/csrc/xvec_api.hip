@@ -76,7 +76,9 @@ struct Layer {
   DevBuf wfr;                 // same values, MFMA-fragment-major: [Npad/32][Kpad/32][plane*2+channel tile][64 lanes][16 B]
   DevBuf wsb;                 // split-blocked bf16 hi/lo [Npad][Kpad/32][128 B] (bf16x3 kernel)
   bool use_split = false;     // this layer runs on the bf16x3 kernel
-  bool im2col = false;        // first layer in bf16x3 mode: fp32 frames -> SB im2col rows -> dense split GEMM
+  bool im2col = false;        // first layer in a split mode: its input is the caller's fp32 feature matrix, staged per forward
+  int cin_pad = 0;            // > 0: staged as SB rows of cin_pad (= cin rounded up to 32) channels per frame and convolved
+                              // like any other w-tap layer (slab reuse across the taps); 0 with im2col: rows materialised
   // ResNet 2-D convolutions on the zero-bordered grid (csrc/grid.hip): 0 = 1-D conv / dense,
   // 1 = 3x3 'same' stride (1,sw), 2 = 1x1 shortcut stride (1,sw), 3 = conv5 (1 x Fin, valid), 4 = conv0 (cin 1)
   int mode = 0;
@@ -625,7 +627,10 @@ void bn_fold(const xv_handle* h, const std::string& scope, int n, std::vector<do
 
 int upload_layer(xv_handle* h, Layer& L) {
   const int K = L.K(), N = L.cout;
-  L.Kpad = (int)align_up(K, 32);
+  // row of the packed weight matrix that holds kernel row k: identity, or tap * cin_pad + channel for a first layer
+  // whose frames are padded to whole 32-channel blocks (the padding rows stay zero)
+  auto krow = [&](int k) { return L.cin_pad ? (k / L.cin) * L.cin_pad + (k % L.cin) : k; };
+  L.Kpad = (int)align_up(L.cin_pad ? L.w * L.cin_pad : K, 32);
   L.Npad = (int)align_up(N, 128);
   const auto& W = T(h, L.kernel_name).data;      // [K][N] (HWIO flattened k-major / [in,out])
   const std::vector<float> no_bias((size_t)N, 0.f);      // resnet convs: use_bias=False (model/resnet.py:31)
@@ -676,15 +681,16 @@ int upload_layer(xv_handle* h, Layer& L) {
     for (int k = 0; k < K; ++k)
       for (int n = 0; n < N; ++n) {
         const float wv = W[(size_t)k * N + n] * wscale;
-        const size_t blk = ((size_t)n * (L.Kpad / 32) + k / 32) * 64;
+        const int kr = krow(k);
+        const size_t blk = ((size_t)n * (L.Kpad / 32) + kr / 32) * 64;
         if (f16) {
           const uint16_t a = f32_to_f16_rn(wv);
-          sb[blk + (k & 31)] = a;
-          sb[blk + 32 + (k & 31)] = f32_to_f16_rn(wv - f16_to_f32(a));
+          sb[blk + (kr & 31)] = a;
+          sb[blk + 32 + (kr & 31)] = f32_to_f16_rn(wv - f16_to_f32(a));
         } else {
           const uint16_t a = f32_to_bf16_rn(wv);
-          sb[blk + (k & 31)] = a;
-          sb[blk + 32 + (k & 31)] = f32_to_bf16_rn(wv - bf16_to_f32(a));
+          sb[blk + (kr & 31)] = a;
+          sb[blk + 32 + (kr & 31)] = f32_to_bf16_rn(wv - bf16_to_f32(a));
         }
       }
     if (wscale != 1.f) {                             // fold 1/s into [bn_scale | ones]; bias / shift are not products
@@ -815,6 +821,7 @@ int xv_finalize(xv_handle* h) {
     const bool bf = h->desc.precision != XV_PREC_F32;       // a split format: bf16x3 or f16x3
     if (L.mode == 0) {
       L.im2col = bf && op.in0 == 0;
+      L.cin_pad = (L.im2col && L.w <= 9) ? (int)align_up(L.cin, 32) : 0;
       L.use_split = L.im2col || (bf && vin.frame_level && (L.w == 1 || (L.cin % 32 == 0 && L.w <= 9)));   // slab halo of the split kernel
     } else {      // grid convolutions: whole SB blocks per tap; conv0 goes through its own im2col
       L.use_split = bf && (L.mode == 4 || L.cin % 32 == 0);
@@ -1093,7 +1100,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       if (L.mode == 4) {
         scratch = ((int64_t)st.M + kSlackRows) * 32 * 4;              // conv0 im2col rows (K = 9 padded to 32)
       } else if (L.im2col) {
-        scratch = (st.M + kSlackRows) * (int64_t)L.Kpad * 4;
+        scratch = L.cin_pad ? (st.rows_in + kSlackRows) * (int64_t)L.cin_pad * 4 : (st.M + kSlackRows) * (int64_t)L.Kpad * 4;
       } else if (!L.use_split && op.out != fused_value) {
         st.ksplit = gemm_f32_ksplit(st.M, L.Kpad, L.Npad);
         if (st.ksplit > 1) scratch = (int64_t)st.ksplit * st.M * L.Npad * 4;
@@ -1453,6 +1460,19 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           // 30-dim first layer on the split kernel: materialise the w*cin-wide rows once (SB
           // format, K padded to 32), then it is a dense layer on those rows
           if (st.scratch_off < 0) return fail(h, XV_ERR_STATE, "im2col layer has no scratch");
+          if (L.cin_pad) {
+            // the 30-dim feature rows become SB rows of one 32-channel block (9.8 MB for 256 x 300 frames instead of the
+            // 48 MB of materialised 5-frame rows); the layer is then an ordinary 5-tap convolution over them
+            XV_HIP(h, launch_im2col_sb(feats, feat_ld, L.cin, 1, st.rows_in, ws + st.scratch_off, L.cin_pad, f16,
+                                       static_cast<int*>(h->ovf_flag.p), s));
+            a.Xsb = ws + st.scratch_off;
+            a.ldsbx = L.cin_pad;
+            a.cin = L.cin_pad;
+            a.K = L.w * L.cin_pad;
+            a.Wsb = L.wsb.p; a.Wfr = L.wfr.p;
+            XV_HIP(h, launch_gemm_bf16x3(a, s));
+            break;
+          }
           XV_HIP(h, launch_im2col_sb(feats, feat_ld, L.cin, L.w, st.M, ws + st.scratch_off, L.Kpad, f16, static_cast<int*>(h->ovf_flag.p), s));
           a.Xsb = ws + st.scratch_off;
           a.ldsbx = L.Kpad;
