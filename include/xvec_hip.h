@@ -108,8 +108,8 @@ typedef struct {
   int32_t resnet_blocks[4];         /* resnet_18: blocks per stage, default [2,2,2,2] (model/resnet.py:203-204);
                                        `channels` is then the width of stage 1 (64)            */
   int32_t resnet_maxpooling;        /* 3x3 stride-1 'same' max-pool behind conv0 (model/resnet.py:230-231)            */
-  int32_t resnet_time_stride;       /* stride 2 along time in the first block of stages 2-4 (:187): not implemented,
-                                       xv_create answers XV_ERR_UNSUPPORTED                     */
+  int32_t resnet_time_stride;       /* stride 2 along time in the first block of stages 2-4 (:187,239,244,249): utterance b
+                                       has ceil(L_b / 8) frames behind stage 4 (tf 'same')        */
 } xv_model_desc;
 
 typedef struct {

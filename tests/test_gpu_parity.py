@@ -245,15 +245,32 @@ def test_ragged_batch_matches_per_utterance(stat_model, precision):
     tr.close()
 
 
-def test_resnet_time_stride_is_refused():
-    """resnet_time_stride (model/resnet.py:187) is the one graph option of the path that is not built: it must raise,
-    not be approximated."""
+@pytest.mark.parametrize("width,precision", [(8, "f32"), (32, "f32"), (32, "bf16x3"), (32, "f16x3")])
+def test_resnet18_time_stride_every_block(width, precision):
+    """resnet_time_stride (model/resnet.py:187,239,244,249): stride 2 along time in the first block of stages 2-4 under
+    TensorFlow's 'same' padding, whose placement depends on the parity of each utterance's length (even: 0 before / 1
+    after, odd: 1 / 1).  Ragged batch with even and odd lengths at every level (16 -> 8 -> 4 -> 2, 9 -> 5 -> 3 -> 2,
+    14 -> 7 -> 4 -> 2, 3 -> 2 -> 1 -> 1, 1 -> 1 -> 1 -> 1), every block output against the oracle."""
+    import torch
     from tf_kaldi_speaker_amd import synth
-    from tf_kaldi_speaker_amd.params import Params
-    from tf_kaldi_speaker_amd.trainer import Trainer
-    tr = Trainer(Params(**dict(synth.RESNET_PARAMS, resnet_time_stride=True)), None, 40, single_cpu=True, device=0)
-    with pytest.raises(NotImplementedError):
-        tr.build("predict")
+    params = dict(synth.RESNET_PARAMS, num_nodes_pooling_layer=96, network_relu_type="lrelu", resnet_time_stride=True,
+                  resnet_maxpooling=True)
+    weights = synth.synth_resnet_weights(params, seed=7, width=width)
+    lens = [16, 9, 14, 3, 1]
+    utts = synth.synth_features(len(lens), lens, 40, seed=17)
+    tr, _ = _trainer(params, weights, 40, precision)
+    packed = torch.from_numpy(np.concatenate(utts, axis=0)).cuda()
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    eps = [ref_numpy.entire_network(u[None], weights, params)[1] for u in utts]
+    assert eps[1]["conv2a"].shape[1] == 5 and eps[1]["conv4a"].shape[1] == 2 and eps[3]["conv5_relu"].shape[1] == 1
+    for name in eps[0]:
+        got = tr.predict_packed(packed, offsets, node=name).cpu().numpy()
+        ref = np.concatenate([e[name].reshape(-1, e[name].shape[-1]) for e in eps], axis=0)
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        err = _rel(got, ref)
+        _note("resnet_ts_w%d" % width, precision, name, err)
+        assert err <= TOL, (name, err)
+    tr.close()
 
 
 def test_too_short_utterance_raises(stat_model):

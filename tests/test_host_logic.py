@@ -134,7 +134,7 @@ def test_trainer_refuses_unsupported_graphs_and_missing_gpu():
     from tf_kaldi_speaker_amd.trainer import Trainer
     with pytest.raises(NotImplementedError):
         Trainer(Params(**dict(synth.TDNN_STAT_PARAMS, network_type="tdnn-s")), None, 30)
-    rn = Trainer(Params(**dict(synth.RESNET_PARAMS, resnet_time_stride=True)), None, 40)
+    rn = Trainer(Params(**dict(synth.RESNET_PARAMS, pooling_type="self_attention")), None, 40)
     with pytest.raises(NotImplementedError):
         rn.build("predict")
     with pytest.raises(NotImplementedError):

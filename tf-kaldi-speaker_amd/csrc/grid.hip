@@ -41,6 +41,27 @@ __global__ void rowmap_grid_kernel(const int32_t* __restrict__ off0, int B, int 
   rowmap[m] = (t < L && j < Fout) ? pos : (cover ? -pos - 2 : -1);
 }
 
+// The same for a convolution that also strides TIME by 2 (resnet_time_stride, model/resnet.py:187).  The GEMM rows still
+// enumerate every padded input time row t (at frequency stride 2); a row produces output frame t_o when it is the top row
+// of that frame's window under TensorFlow's 'same' padding, which depends on the parity of the utterance's length:
+//   3 x 3 (ktime = 3): L even pads (0, 1) -> window rows 2 t_o .. 2 t_o + 2 of the input = grid rows t = 2 t_o + 1 .. :
+//                      t odd, t_o = (t - 1) / 2;   L odd pads (1, 1) -> grid rows t = 2 t_o .. : t even, t_o = t / 2
+//   1 x 1 (ktime = 1): no padding, input row 2 t_o (the A operand already points at the window centre): t even, t_o = t / 2
+// The other rows are skipped (-1): the caller zeroes the output as a whole.
+__global__ void rowmap_grid_ts_kernel(const int32_t* __restrict__ off_in, const int32_t* __restrict__ off_out, int B,
+                                      int rows_per_t, int Fout, int So, int ktime, int32_t* __restrict__ rowmap, int64_t M) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int b = find_utt(off_in, B, rows_per_t, m);
+  const int64_t local = m - (int64_t)(off_in[b] + 2 * b) * rows_per_t;
+  const int t = (int)(local / rows_per_t), j = (int)(local - (int64_t)t * rows_per_t);
+  const int Lin = off_in[b + 1] - off_in[b], Lout = off_out[b + 1] - off_out[b];
+  const int first = (ktime == 3 && (Lin & 1) == 0) ? 1 : 0;       // grid row of the window top of output frame 0
+  const int to = (t - first) >> 1;
+  const bool valid = t >= first && ((t - first) & 1) == 0 && to < Lout && j < Fout;
+  rowmap[m] = valid ? (int32_t)((int64_t)(off_out[b] + 2 * b) * So + (int64_t)(to + 1) * So + j + 1) : -1;
+}
+
 __global__ void rowmap_rows_kernel(const int32_t* __restrict__ off0, int B, int32_t* __restrict__ rowmap, int64_t M) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
@@ -167,6 +188,14 @@ hipError_t launch_build_rowmap_grid(const int32_t* off0, int B, int rows_per_t, 
   if (M <= 0) return hipSuccess;
   hipLaunchKernelGGL(rowmap_grid_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, off0, B, rows_per_t, Fout, So,
                      cover, rowmap, M);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_rowmap_grid_ts(const int32_t* off_in, const int32_t* off_out, int B, int rows_per_t, int Fout, int So,
+                                       int ktime, int32_t* rowmap, int64_t M, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rowmap_grid_ts_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, off_in, off_out, B, rows_per_t,
+                     Fout, So, ktime, rowmap, M);
   return hipGetLastError();
 }
 

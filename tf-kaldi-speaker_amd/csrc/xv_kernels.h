@@ -142,6 +142,10 @@ hipError_t launch_pool_finalize(const float* part, int C, const int32_t* off0, i
 //   positions: encoded "write zeros" (-pos - 2) when cover (rows_per_t == So), else -1 (the caller zeroes the value)
 hipError_t launch_build_rowmap_grid(const int32_t* off0, int B, int rows_per_t, int Fout, int So, int cover, int32_t* rowmap,
                                     int64_t M, hipStream_t s);
+// the same when the convolution also strides time by 2 (off_in / off_out: frame offsets at the input / output time level;
+// ktime 3 = 3x3 'same', 1 = 1x1 shortcut); rows that produce no output frame are skipped (-1)
+hipError_t launch_build_rowmap_grid_ts(const int32_t* off_in, const int32_t* off_out, int B, int rows_per_t, int Fout, int So,
+                                       int ktime, int32_t* rowmap, int64_t M, hipStream_t s);
 // rowmap of conv5 (1 x F valid): rows enumerate padded time rows; valid iff 1 <= t' <= L_b -> frame off0[b]+t'-1
 hipError_t launch_build_rowmap_rows(const int32_t* off0, int B, int32_t* rowmap, int64_t M, hipStream_t s);
 // rowmap of conv0 (rows = grid positions, pitch S): interior -> same position, border -> zeros at the same position

@@ -83,6 +83,7 @@ struct Layer {
   // 1 = 3x3 'same' stride (1,sw), 2 = 1x1 shortcut stride (1,sw), 3 = conv5 (1 x Fin, valid), 4 = conv0 (cin 1)
   int mode = 0;
   int Fin = 0, Fout = 0, sw = 1;
+  int st = 1;                 // stride along time of a grid convolution (2: first block of stages 2-4 under resnet_time_stride)
   bool has_bias = true;
   int K() const { return mode == 1 ? 9 * cin : (mode == 3 ? Fin * cin : (mode == 4 ? 9 : w * cin)); }
   DevBuf vec;                 // [bias | bn_scale | bn_shift | alpha | ones] each cout floats
@@ -111,7 +112,8 @@ struct Value {
   int grid_F = 0;     // > 0: zero-bordered grid value with grid_F frequency bins (rows = (F0+2B)*grid_S)
   int grid_S = 0;     // its pitch: positions per padded time row (csrc/grid.hip: F + 1, or F + 2 under a stride-2 reader)
   bool frame_level = true;
-  int ctx = 0;        // temporal context consumed (frame-level values): rows = F0 - B*ctx
+  int ctx = 0;        // temporal context consumed (frame-level values): rows = F[tlevel] - B*ctx
+  int tlevel = 0;     // time resolution: utterance b has ceil(L_b / 2^tlevel) frames (resnet_time_stride; else 0)
   int cols = 0;
 };
 
@@ -190,6 +192,8 @@ struct PlanStep {
   int ksplit = 1;               // split-K slices of a small-M fp32 GEMM, or of the tail M tiles of a bf16x3 GEMM
   int tail_mt = 0;              // bf16x3: M tiles computed K-split (gemm_bf16x3_tail_plan)
   bool fuse_pool = false;       // GEMM: emit pooling partials instead of activations; STAT_POOL: finalize only
+  int lvl_in = 0, lvl_out = 0;  // time level of the input / output value
+  int64_t frames_out = 0;       // total frames of the batch at the output's time level
   bool grid_cover = false;      // grid-valued output whose border is re-zeroed by zero-writing GEMM rows (no memset)
   int fuse_att = 0;             // GEMM: 1 = score partials instead of the key, 2 = weighted moments instead of the value;
                                 // ATT_SCORES / ATT_SOFTMAX / ATT_POOL: 1 = the fused form of that op
@@ -206,6 +210,11 @@ struct xv_plan {
   std::vector<int32_t> offsets;     // host copy
   std::vector<int32_t> offsets_slotbase;
   DevBuf d_offsets;                 // [B+1]
+  std::vector<int32_t> lvl_offsets[4];   // frame offsets per time level (level 0 = offsets); levels > 0 only under resnet_time_stride
+  DevBuf d_lvl[4];                  // device copies of levels 1..3 ([0] unused: level 0 is d_offsets)
+  const int32_t* dev_offsets(int level) const {
+    return static_cast<const int32_t*>(level > 0 ? d_lvl[level].p : d_offsets.p);
+  }
   DevBuf d_rowmaps;                 // concatenated row maps
   std::vector<int64_t> rowmap_off;  // element offsets into d_rowmaps
   std::vector<PlanStep> steps;
@@ -380,9 +389,10 @@ void add_node(xv_handle* h, const std::string& name, int op, int stage, bool att
 
 // one ResNet convolution (+BN, + optional activation / residual); returns the output value id
 int add_conv2d(xv_handle* h, const std::string& var, const std::string& bn, const std::string& relu, int mode, int cin,
-               int cout, int Fin, int Fout, int sw, int act, int in_value, int residual_value, const char* node_name) {
+               int cout, int Fin, int Fout, int sw, int act, int in_value, int residual_value, const char* node_name,
+               int st = 1) {
   Layer L;
-  L.mode = mode; L.cin = cin; L.cout = cout; L.Fin = Fin; L.Fout = Fout; L.sw = sw; L.w = 1;
+  L.mode = mode; L.cin = cin; L.cout = cout; L.Fin = Fin; L.Fout = Fout; L.sw = sw; L.w = 1; L.st = st;
   L.kernel_name = var + "/kernel";
   L.has_bias = (mode == 3);
   if (mode == 1 || mode == 4) expect(h, L.kernel_name, {3, 3, cin, cout});
@@ -398,6 +408,7 @@ int add_conv2d(xv_handle* h, const std::string& var, const std::string& bn, cons
   const int li = (int)h->layers.size();
   h->layers.push_back(std::move(L));
   Value v; v.cols = cout;
+  v.tlevel = h->values[in_value].tlevel + (st == 2 ? 1 : 0);
   if (mode == 3) { v.frame_level = true; v.ctx = 0; } else { v.grid_F = Fout; }
   const int vid = (int)h->values.size();
   h->values.push_back(v);
@@ -416,7 +427,6 @@ int build_resnet(xv_handle* h) {
   const int act = act_of(d);
   const std::string sc = "resnet_18/";
   if (d.feat_dim != 40) return fail(h, XV_ERR_INVALID, "resnet_18 needs 40-dim features (model/resnet.py:190)");
-  if (d.resnet_time_stride) return fail(h, XV_ERR_UNSUPPORTED, "resnet_time_stride is not implemented");
   if (d.pooling_type != XV_POOL_STATISTICS)
     return fail(h, XV_ERR_UNSUPPORTED, "resnet_18 registers no frame-level endpoints: only statistics_pooling is possible");
   h->values.clear();
@@ -442,10 +452,11 @@ int build_resnet(xv_handle* h) {
       if (bi == 0) snprintf(nm, sizeof(nm), "conv%da", stage); else snprintf(nm, sizeof(nm), "conv%db_%d", stage, bi - 1);
       const std::string b = sc + nm;
       const int s_w = bi == 0 ? sw : 1, Fi = bi == 0 ? F : Fo;
-      const int c0 = add_conv2d(h, b + "_conv0", b + "_bn0", b + "_relu0", 1, cin, nf, Fi, Fo, s_w, act, v, -1, nullptr);
+      const int s_t = (bi == 0 && stage > 1 && d.resnet_time_stride) ? 2 : 1;       // model/resnet.py:187,239,244,249
+      const int c0 = add_conv2d(h, b + "_conv0", b + "_bn0", b + "_relu0", 1, cin, nf, Fi, Fo, s_w, act, v, -1, nullptr, s_t);
       int shortcut = v;
       if (bi == 0)      // projection shortcut: 1x1 conv + BN (model/resnet.py:71-83)
-        shortcut = add_conv2d(h, b + "_conv_short", b + "_bn_short", "", 2, cin, nf, Fi, Fo, s_w, ACT_NONE, v, -1, nullptr);
+        shortcut = add_conv2d(h, b + "_conv_short", b + "_bn_short", "", 2, cin, nf, Fi, Fo, s_w, ACT_NONE, v, -1, nullptr, s_t);
       v = add_conv2d(h, b + "_conv1", b + "_bn1", b + "_relu_final", 1, nf, nf, Fo, Fo, 1, act, c0, shortcut, nm);
       cin = nf;
     }
@@ -464,7 +475,7 @@ int build_resnet(xv_handle* h) {
     L.ep[ST_ACT] = std::string(name) + "_relu";
     const int li = (int)h->layers.size();
     h->layers.push_back(std::move(L));
-    Value vv; vv.frame_level = true; vv.ctx = 0; vv.cols = co;
+    Value vv; vv.frame_level = true; vv.ctx = 0; vv.cols = co; vv.tlevel = h->values[in_v].tlevel;
     const int vid = (int)h->values.size();
     h->values.push_back(vv);
     Op op; op.kind = OP_GEMM; op.layer = li; op.in0 = in_v; op.out = vid;
@@ -719,22 +730,23 @@ int upload_layer(xv_handle* h, Layer& L) {
   return XV_OK;
 }
 
-int64_t value_rows(const xv_handle* h, int vid, int64_t F0, int B) {
+// Fl[k] = total frames of the batch at time level k (Fl[0] = frame_offsets[B])
+int64_t value_rows(const xv_handle* h, int vid, const int64_t* Fl, int B) {
   const Value& v = h->values[vid];
-  if (v.grid_F > 0) return (F0 + 2 * (int64_t)B) * v.grid_S;
-  return v.frame_level ? F0 - (int64_t)B * v.ctx : B;
+  if (v.grid_F > 0) return (Fl[v.tlevel] + 2 * (int64_t)B) * v.grid_S;
+  return v.frame_level ? Fl[v.tlevel] - (int64_t)B * v.ctx : B;
 }
 
-int64_t value_bytes(const xv_handle* h, int vid, int64_t F0, int B) {
+int64_t value_bytes(const xv_handle* h, int vid, const int64_t* Fl, int B) {
   const Value& v = h->values[vid];
-  return align_up((value_rows(h, vid, F0, B) + kSlackRows) * (int64_t)v.cols * 4, kAlign);
+  return align_up((value_rows(h, vid, Fl, B) + kSlackRows) * (int64_t)v.cols * 4, kAlign);
 }
 
 int sb_ld(int cols) { return (int)align_up(cols, 32); }
 
-int64_t value_sb_bytes(const xv_handle* h, int vid, int64_t F0, int B) {
+int64_t value_sb_bytes(const xv_handle* h, int vid, const int64_t* Fl, int B) {
   const Value& v = h->values[vid];
-  return align_up((value_rows(h, vid, F0, B) + kSlackRows) * (int64_t)sb_ld(v.cols) * 4, kAlign);
+  return align_up((value_rows(h, vid, Fl, B) + kSlackRows) * (int64_t)sb_ld(v.cols) * 4, kAlign);
 }
 
 }  // namespace
@@ -925,6 +937,18 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
   }
   const int64_t F0 = frame_offsets[batch];
   if (F0 > (int64_t)1 << 30) return fail(h, XV_ERR_INVALID, "batch of %lld frames is too large for 32-bit row indices", (long long)F0);
+  // frame offsets per time level (tf 'same' with stride 2: ceil(L / 2) frames; model/resnet.py:187)
+  int max_level = 0;
+  for (const Value& v : h->values) max_level = std::max(max_level, v.tlevel);
+  std::vector<int32_t> lvl[4];
+  int64_t Fl[4] = {F0, F0, F0, F0};
+  lvl[0].assign(frame_offsets, frame_offsets + batch + 1);
+  for (int k = 1; k <= max_level && k < 4; ++k) {
+    lvl[k].resize(batch + 1);
+    lvl[k][0] = 0;
+    for (int b = 0; b < batch; ++b) lvl[k][b + 1] = lvl[k][b] + (lvl[k - 1][b + 1] - lvl[k - 1][b] + 1) / 2;
+    Fl[k] = lvl[k][batch];
+  }
 
   // ops needed for this node (backward closure), then in topological (= creation) order
   std::vector<char> need(h->ops.size(), 0);
@@ -944,6 +968,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
   if (!p) return fail(h, XV_ERR_HIP, "out of host memory");
   p->h = h;
   p->offsets.assign(frame_offsets, frame_offsets + batch + 1);
+  for (int k = 0; k <= max_level && k < 4; ++k) p->lvl_offsets[k] = lvl[k];
   p->uniform_len = uniform;
   p->uniform_L = frame_offsets[1] - frame_offsets[0];
 
@@ -1051,10 +1076,11 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
   const int slot_value = fused_value >= 0 ? fused_value : att_pool_value;   // the value whose rows are pooled per 64-row slot
   if (slot_value >= 0) {
     const int ctx = h->values[slot_value].ctx;
+    const std::vector<int32_t>& so = lvl[h->values[slot_value].tlevel];
     std::vector<int32_t> slotbase(batch);
     int64_t nslots = 0;
     for (int b = 0; b < batch; ++b) {
-      const int r0 = frame_offsets[b] - b * ctx, r1 = frame_offsets[b + 1] - (b + 1) * ctx;
+      const int r0 = so[b] - b * ctx, r1 = so[b + 1] - (b + 1) * ctx;
       const int t0 = r0 >> 6, t1 = (r1 - 1) >> 6;
       slotbase[b] = (int32_t)(nslots - t0);
       nslots += t1 - t0 + 1;
@@ -1071,29 +1097,32 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     int64_t step_scratch = 0;            // released once this step's outputs are placed
     st.op = order[s];
     st.to_out = (order[s] == node.op);
-    st.rows_in = op.in0 >= 0 ? value_rows(h, op.in0, F0, batch) : 0;
-    st.rows_out = value_rows(h, op.out, F0, batch);
+    st.rows_in = op.in0 >= 0 ? value_rows(h, op.in0, Fl, batch) : 0;
+    st.rows_out = value_rows(h, op.out, Fl, batch);
+    st.lvl_in = op.in0 >= 0 ? h->values[op.in0].tlevel : 0;
+    st.lvl_out = h->values[op.out].tlevel;
+    st.frames_out = Fl[st.lvl_out];
     st.in0_off = op.in0 == 0 ? -2 : (op.in0 > 0 ? voff[op.in0] : -1);
     st.in0_sb_off = op.in0 > 0 ? voff_sb[op.in0] : -1;
     st.in1_off = op.in1 > 0 ? voff[op.in1] : -1;
     if (op.kind == OP_GEMM) {
       const Layer& L = h->layers[op.layer];
       st.stage = st.to_out ? node.stage : L.final_stage();
-      const int64_t padded_rows = F0 + 2 * (int64_t)batch;           // time rows incl. the two border rows per utterance
+      const int64_t padded_rows = Fl[st.lvl_in] + 2 * (int64_t)batch;   // input time rows incl. the two border rows per utterance
       if (L.mode == 0) st.M = (int)(st.rows_in - (L.w - 1));
       else if (L.mode == 1 || L.mode == 2) st.M = (int)(padded_rows * (h->values[op.in0].grid_S / L.sw));
       else if (L.mode == 3) st.M = (int)padded_rows;
       else st.M = (int)(padded_rows * h->values[op.out].grid_S);     // conv0: one row per output grid position
       // does every border position of the output get a zero-writing GEMM row? (csrc/grid.hip)  If not the value is
       // zeroed as a whole before the layer runs.
-      if (L.mode == 1 || L.mode == 2) st.grid_cover = h->values[op.in0].grid_S / L.sw == h->values[op.out].grid_S;
+      if (L.mode == 1 || L.mode == 2) st.grid_cover = L.st == 1 && h->values[op.in0].grid_S / L.sw == h->values[op.out].grid_S;
       else if (L.mode == 4) st.grid_cover = true;
       if (L.w > 1 || L.mode != 0) {
         st.rowmap = (int)p->rowmap_off.size();
         p->rowmap_off.push_back(rowmap_elems);
         rowmap_elems += align_up(st.M, 64);
       }
-      const int64_t valid_out = L.mode == 0 ? st.rows_out : F0 * (L.mode == 3 ? 1 : L.Fout);
+      const int64_t valid_out = L.mode == 0 ? st.rows_out : Fl[st.lvl_out] * (L.mode == 3 ? 1 : L.Fout);
       st.flops = 2 * valid_out * (int64_t)L.cout * L.K();
       st.bytes = 4 * (st.rows_in * L.cin + st.rows_out * L.cout + (int64_t)L.K() * L.cout);
       int64_t scratch = 0;
@@ -1153,7 +1182,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       st.out_off = -1;                   // straight into the caller's output buffer (fp32)
     } else if (st.to_out && !node.att_weights) {
       st.unpad_to_out = true;            // grid-valued node: padded grid in the workspace, then unpad into `out`
-      vsize[op.out] = value_bytes(h, op.out, F0, batch);
+      vsize[op.out] = value_bytes(h, op.out, Fl, batch);
       voff[op.out] = arena_alloc(vsize[op.out]);
       st.out_off = voff[op.out];
     } else {
@@ -1180,7 +1209,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
         voff[op.out] = arena_alloc(vsize[op.out]);
         st.out_off = voff[op.out];
       } else if (want_f32[op.out] || node.att_weights) {
-        vsize[op.out] = value_bytes(h, op.out, F0, batch);
+        vsize[op.out] = value_bytes(h, op.out, Fl, batch);
         if (op.kind == OP_ATT_SCORES && val_prod >= 0)       // + the per-slot weight sums written by the softmax step
           vsize[op.out] = align_up(st.rows_out * (int64_t)h->desc.att_num_heads * 4, kAlign) +
                           align_up(p->pool_slots * (int64_t)h->desc.att_num_heads * 4, kAlign) + kAlign;
@@ -1188,7 +1217,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
         st.out_off = voff[op.out];
       }
       if (want_sb[op.out]) {
-        vsize_sb[op.out] = value_sb_bytes(h, op.out, F0, batch);
+        vsize_sb[op.out] = value_sb_bytes(h, op.out, Fl, batch);
         voff_sb[op.out] = arena_alloc(vsize_sb[op.out]);
         st.out_sb_off = voff_sb[op.out];
       }
@@ -1227,11 +1256,11 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     I.out_cols = p->uniform_L - vout.ctx;
   } else if (vout.grid_F > 0) {
     I.frame_level = 1;
-    I.out_rows = F0 * vout.grid_F;       // [sum L_b, F, C] without the border
+    I.out_rows = Fl[vout.tlevel] * vout.grid_F;       // [sum L_b, F, C] without the border
     I.out_cols = vout.cols;
   } else {
     I.frame_level = vout.frame_level ? 1 : 0;
-    I.out_rows = value_rows(h, top.out, F0, batch);
+    I.out_rows = value_rows(h, top.out, Fl, batch);
     I.out_cols = vout.cols;
   }
   I.workspace_bytes = align_up(arena_top, kAlign) + kAlign;
@@ -1248,6 +1277,11 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
   if ((e = pool_take(h, (size_t)(batch + 1) * 4, p->d_offsets)) != hipSuccess) return bail(e, "hipMalloc(offsets)");
   if ((e = hipMemcpyAsync(p->d_offsets.p, p->offsets.data(), (size_t)(batch + 1) * 4, hipMemcpyHostToDevice, s)) != hipSuccess)
     return bail(e, "hipMemcpyAsync(offsets)");
+  for (int k = 1; k <= max_level && k < 4; ++k) {
+    if ((e = pool_take(h, (size_t)(batch + 1) * 4, p->d_lvl[k])) != hipSuccess) return bail(e, "hipMalloc(level offsets)");
+    if ((e = hipMemcpyAsync(p->d_lvl[k].p, p->lvl_offsets[k].data(), (size_t)(batch + 1) * 4, hipMemcpyHostToDevice, s)) != hipSuccess)
+      return bail(e, "hipMemcpyAsync(level offsets)");
+  }
   if (rowmap_elems > 0) {
     if ((e = pool_take(h, (size_t)rowmap_elems * 4, p->d_rowmaps)) != hipSuccess) return bail(e, "hipMalloc(rowmaps)");
     for (const PlanStep& st : p->steps) {
@@ -1255,9 +1289,12 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       const Op& op = h->ops[st.op];
       const Layer& L = h->layers[op.layer];
       const int ctx_in = h->values[op.in0].ctx;
-      const int32_t* doff = static_cast<const int32_t*>(p->d_offsets.p);
+      const int32_t* doff = p->dev_offsets(st.lvl_in);
       int32_t* rm = static_cast<int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.rowmap];
       if (L.mode == 0) e = launch_build_rowmap(doff, batch, ctx_in, L.w, rm, st.M, s);
+      else if ((L.mode == 1 || L.mode == 2) && L.st == 2)
+        e = launch_build_rowmap_grid_ts(doff, p->dev_offsets(st.lvl_out), batch, h->values[op.in0].grid_S / L.sw, L.Fout,
+                                        h->values[op.out].grid_S, L.mode == 1 ? 3 : 1, rm, st.M, s);
       else if (L.mode == 1 || L.mode == 2)
         e = launch_build_rowmap_grid(doff, batch, h->values[op.in0].grid_S / L.sw, L.Fout, h->values[op.out].grid_S,
                                      st.grid_cover ? 1 : 0, rm, st.M, s);
@@ -1268,12 +1305,12 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
   }
   if (slot_value >= 0) {
     const int ctx = h->values[slot_value].ctx;
-    const int64_t rows = value_rows(h, slot_value, F0, batch);
+    const int64_t rows = value_rows(h, slot_value, Fl, batch);
     if ((e = pool_take(h, (size_t)rows * 4, p->d_row2utt)) != hipSuccess) return bail(e, "hipMalloc(row2utt)");
     if ((e = pool_take(h, (size_t)batch * 4, p->d_slotbase)) != hipSuccess) return bail(e, "hipMalloc(slotbase)");
     if ((e = hipMemcpyAsync(p->d_slotbase.p, p->offsets_slotbase.data(), (size_t)batch * 4, hipMemcpyHostToDevice, s)) != hipSuccess)
       return bail(e, "hipMemcpyAsync(slotbase)");
-    if ((e = launch_build_row2utt(static_cast<const int32_t*>(p->d_offsets.p), batch, ctx,
+    if ((e = launch_build_row2utt(p->dev_offsets(h->values[slot_value].tlevel), batch, ctx,
                                   static_cast<int32_t*>(p->d_row2utt.p), (int)rows, s)) != hipSuccess)
       return bail(e, "build_row2utt");
   }
@@ -1294,6 +1331,7 @@ void xv_plan_destroy(xv_plan* p) {
   {
     DeviceGuard g(p->h->device);
     pool_give(p->h, p->d_offsets);
+    for (int k = 1; k < 4; ++k) pool_give(p->h, p->d_lvl[k]);
     pool_give(p->h, p->d_rowmaps);
     pool_give(p->h, p->d_row2utt);
     pool_give(p->h, p->d_slotbase);
@@ -1362,6 +1400,8 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
       return o == -2 ? feats : reinterpret_cast<const float*>(ws + o);
     };
     float* optr = st.out_off >= 0 ? reinterpret_cast<float*>(ws + st.out_off) : out;
+    const int32_t* off_in = p->dev_offsets(st.lvl_in);      // frame offsets at the time level of the step's input / output
+    const int32_t* off_out = p->dev_offsets(st.lvl_out);
     (void)split;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     const bool prof_step = prof && (!h->opt_profile_dominant || (int)si == p->dominant_step);
@@ -1395,7 +1435,9 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           // for the first utterance's top border row and first left border (S + 1 positions no GEMM row maps to);
           // otherwise the whole value is zeroed first.
           const size_t head = (size_t)vo.grid_S + 1;
-          const size_t rows0 = st.grid_cover && L.mode != 4 ? head : (st.grid_cover ? 0 : (size_t)st.rows_out);
+          // (whole-value clear: one more time row than the value has -- with the shared border column the 3x3 window of
+          // the last bin of the last utterance's bottom border row reads position (L + 2, 0), just behind the grid)
+          const size_t rows0 = st.grid_cover && L.mode != 4 ? head : (st.grid_cover ? 0 : (size_t)st.rows_out + vo.grid_S);
           if (rows0 > 0) {
             if (st.out_off >= 0) XV_HIP(h, hipMemsetAsync(ws + st.out_off, 0, rows0 * L.cout * 4, s));
             if (st.out_sb_off >= 0) XV_HIP(h, hipMemsetAsync(ws + st.out_sb_off, 0, rows0 * sb_ld(L.cout) * 4, s));
@@ -1452,8 +1494,8 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
             XV_HIP(h, launch_gemm_f32(a, true, s));
           }
           if (st.unpad_to_out)
-            XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.grid_S, vo.cols,
-                                          p->info.in_frames, out, s));
+            XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off_out, B, vo.grid_F, vo.grid_S, vo.cols,
+                                          st.frames_out, out, s));
           break;
         }
         if (L.im2col) {
@@ -1493,8 +1535,8 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           }
           XV_HIP(h, launch_gemm_bf16x3(a, s));
           if (st.unpad_to_out)
-            XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.grid_S, vo.cols,
-                                          p->info.in_frames, out, s));
+            XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off_out, B, vo.grid_F, vo.grid_S, vo.cols,
+                                          st.frames_out, out, s));
           break;
         }
         if (st.ksplit > 1 && st.scratch_off >= 0) {
@@ -1506,18 +1548,18 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           return fail(h, XV_ERR_UNSUPPORTED, "resnet convolution %s needs channel counts that are multiples of 4", L.kernel_name.c_str());
         XV_HIP(h, launch_gemm_f32(a, aligned, s));
         if (st.unpad_to_out)
-          XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off, B, vo.grid_F, vo.grid_S, vo.cols,
-                                        p->info.in_frames, out, s));
+          XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off_out, B, vo.grid_F, vo.grid_S, vo.cols,
+                                        st.frames_out, out, s));
         break;
       }
       case OP_STAT_POOL: {
         const Value& vi = h->values[op.in0];
         if (st.fuse_pool) {
-          XV_HIP(h, launch_pool_finalize(in_ptr(st.in0_off), vi.cols, off, B, vi.ctx,
+          XV_HIP(h, launch_pool_finalize(in_ptr(st.in0_off), vi.cols, off_in, B, vi.ctx,
                                          static_cast<const int32_t*>(p->d_slotbase.p), optr, 2 * vi.cols, s));
           break;
         }
-        XV_HIP(h, launch_stat_pool(in_ptr(st.in0_off), vi.cols, vi.cols, off, B, vi.ctx, optr, 2 * vi.cols, s));
+        XV_HIP(h, launch_stat_pool(in_ptr(st.in0_off), vi.cols, vi.cols, off_in, B, vi.ctx, optr, 2 * vi.cols, s));
         break;
       }
       case OP_ATT_SCORES: {
@@ -1570,7 +1612,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
                                          st.out_sb_off >= 0 ? ws + st.out_sb_off : nullptr, sb_ld(vo.cols), f16,
                                          static_cast<int*>(h->ovf_flag.p), s));
         if (st.unpad_to_out)
-          XV_HIP(h, launch_grid_unpad_n(y, off, B, vo.grid_F, vo.grid_S, vo.cols, p->info.in_frames, out, s));
+          XV_HIP(h, launch_grid_unpad_n(y, off_out, B, vo.grid_F, vo.grid_S, vo.cols, st.frames_out, out, s));
         break;
       }
       case OP_L2_SCALE: {

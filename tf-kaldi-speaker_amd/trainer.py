@@ -100,8 +100,6 @@ class Trainer(object):
         if p.network_type == "resnet_18":
             if self.dim != 40:
                 raise AssertionError("resnet_18 needs 40-dim features (model/resnet.py:190)")
-            if p.dict.get("resnet_time_stride", False):
-                raise NotImplementedError("resnet_time_stride is not built (DESIGN.md section 7)")
             if "resnet_blocks" not in p.dict:
                 p.dict["resnet_blocks"] = [2, 2, 2, 2]                                  # model/resnet.py:203-204
             if p.pooling_type != "statistics_pooling":
