@@ -10,12 +10,12 @@ import sys
 
 # 256 x [300, 30]: (kernel substring, threads per launch, sub-index or None) -> layer
 PARTS = [
-    ("w14p2_kernel", 614400, None, "tdnn1_conv"),
-    ("w14p2_kernel", 606208, None, "tdnn2_conv"), ("w14p2_kernel", 598016, None, "tdnn3_conv"),     # without the tail form
+    ("im2col_sb_kernel", 1228800, None, "tdnn1_conv"),                                           # feature rows -> SB rows (staging of L1)
+    ("w14p2_kernel", 614400, None, "tdnn1_conv"),                                                # L1: 5 taps over 32-channel padded rows
     ("w14p2_kernel", 589824, 0, "tdnn2_conv"), ("w14p2_kernel", 589824, 1, "tdnn3_conv"),           # main tiles, tail form
     ("w14p2_tail_kernel", 65536, 0, "tdnn2_conv"), ("w14p2_tail_kernel", 65536, 1, "tdnn3_conv"),
     ("tail_reduce_kernel", 262144, None, "tdnn2_conv"), ("tail_reduce_kernel", 131072, None, "tdnn3_conv"),
-    ("w14p2_kernel", 585728, None, "tdnn4_dense"), ("w14p2_kernel", 1757184, None, "tdnn5_dense"),
+    ("w1p3_kernel", 585728, None, "tdnn4_dense"), ("w1p3_kernel", 1757184, None, "tdnn5_dense"),
 ]
 
 
