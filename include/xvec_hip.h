@@ -63,9 +63,9 @@ enum { XV_ACT_RELU = 0, XV_ACT_LRELU = 1, XV_ACT_PRELU = 2 };
 /* arithmetic of the matrix products */
 enum {
   XV_PREC_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate   */
-  XV_PREC_BF16X3 = 1,  /* 3x v_mfma_f32_32x32x16_bf16 on hi/lo bf16 splits, fp32 accumulate
+  XV_PREC_BF16X3 = 1,  /* 3x v_mfma_f32_16x16x32_bf16 on hi/lo bf16 splits, fp32 accumulate
                           (~5e-6 relative per layer; meets the 1e-4 parity bar at 5x the MFMA rate; full fp32 range) */
-  XV_PREC_F16X3 = 2    /* 3x v_mfma_f32_32x32x16_f16 on hi/lo fp16 splits, fp32 accumulate: same kernels, layout and
+  XV_PREC_F16X3 = 2    /* 3x v_mfma_f32_16x16x32_f16 on hi/lo fp16 splits, fp32 accumulate: same kernels, layout and
                           rate as bf16x3 with 22 instead of 16 significand bits per operand (~3e-7 relative).  Weights
                           are pre-scaled per layer by a power of two into the fp16 range (undone in the epilogue);
                           activations / input features beyond +-65504 overflow to inf -- outputs are then non-finite and
