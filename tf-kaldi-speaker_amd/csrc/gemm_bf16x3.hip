@@ -358,6 +358,55 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(GemmArgs p, int
 // 1 / 2 = the attention forms of xv_epilogue.h (score partials of the last key layer / weighted moments of the value).
 // A separate instantiation keeps the default kernel's code -- and its register allocation -- untouched.
 // F16 selects the split format of both operands (bf16 hi/lo or fp16 hi/lo: same bytes, same MFMA rate).
+// Traffic lab (-DXV_TRAFFIC_LAB=bits, tools/traffic_lab.sh; never in the shipped library; results are WRONG with bits 0/1):
+//   bit 0  every workgroup stages the activation slab of M tile 0      -> FETCH_SIZE shows the weight stream alone
+//   bit 1  every workgroup loads the weight fragments of N tile 0      -> FETCH_SIZE shows the activation stream alone
+//   bit 2  tile order: one N tile per XCD (weights of an XCD stay in its L2; every M tile is staged on nNt XCDs)
+//   bit 3  tile order: an XCD walks its M range once per N tile (N-major phases)
+//   bit 4  tile order: two N tiles per XCD (half of the weights per L2; every M tile is staged on two XCDs)
+#ifndef XV_TRAFFIC_LAB
+#define XV_TRAFFIC_LAB 0
+#endif
+#if (XV_TRAFFIC_LAB & 32)
+#define XV_TLAB_ANT " nt"      // bit 5: slab loads non-temporal (evict-first in L2)
+#else
+#define XV_TLAB_ANT ""
+#endif
+#define XV_TLAB_M0(m0) ((XV_TRAFFIC_LAB & 1) ? 0 : (m0))
+#define XV_TLAB_N0(n0) ((XV_TRAFFIC_LAB & 2) ? 0 : (n0))
+
+// workgroup -> (M tile, N tile).  Product order: ids congruent mod 8 share an XCD; an XCD owns a contiguous run of
+// tiles, N fastest, so the nNt workgroups that stage the same slab start together on the same L2.
+__device__ __forceinline__ void tile_of_block(int id, int nMt, int nNt, int& mt, int& nt) {
+  if constexpr ((XV_TRAFFIC_LAB & 4) != 0) {
+    if (nNt == 4) {                                   // XCD x: N tile x & 3, M tiles of half x >> 2
+      const int x = id & 7, i = id >> 3, h0 = (nMt + 1) >> 1;
+      nt = x & 3;
+      mt = (x >> 2) ? h0 + i : i;
+      return;
+    }
+  }
+  if constexpr ((XV_TRAFFIC_LAB & 8) != 0) {
+    if ((nMt & 7) == 0) {                             // XCD x: M tiles [x * nMt/8, (x+1) * nMt/8), N-major
+      const int x = id & 7, i = id >> 3, per = nMt >> 3;
+      nt = i / per;
+      mt = x * per + (i - nt * per);
+      return;
+    }
+  }
+  if constexpr ((XV_TRAFFIC_LAB & 16) != 0) {
+    if (nNt == 4 && (nMt & 3) == 0) {                 // XCD x: N tiles 2(x&1), 2(x&1)+1; M quarter x >> 1
+      const int x = id & 7, i = id >> 3, per = nMt >> 2;
+      nt = 2 * (x & 1) + (i & 1);
+      mt = (x >> 1) * per + (i >> 1);
+      return;
+    }
+  }
+  const int tile = xcd_remap(id, nMt * nNt);
+  mt = tile / nNt;
+  nt = tile - mt * nNt;
+}
+
 template <int NPS, int EPI = 0, bool F16 = false>
 __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, int w, char* smem3, int cb_begin, int cb_end) {
   char* As = smem3;
@@ -373,16 +422,16 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
   const int64_t a_row_bytes = (p.a_pitch ? p.a_pitch : p.ldsbx) * 4;
   const int kbt = p.a_pitch ? (p.ktap >> 5) : (p.Kpad >> 5);
   const int64_t tap_bytes = p.a_pitch ? p.tap_stride * 4 : 0;
-  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(m0 + lrow) * a_row_bytes;
+  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(XV_TLAB_M0(m0) + lrow) * a_row_bytes;
   const int64_t nkb4k = (int64_t)(p.Kpad >> 5) * 4096;
-  const char* Wg = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((n0 >> 5) + wave) * nkb4k + lane * 16;
+  const char* Wg = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((XV_TLAB_N0(n0) >> 5) + wave) * nkb4k + lane * 16;
   const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr_t)As;
 
   auto dma_a = [&](int64_t koff, int buf, int g) {
     const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
     const char* src = Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * DA_BYTES + g * 1024);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" XV_TLAB_ANT ::"v"(src), "s"(dst) : "memory");
   };
 
   f32x4 acc[8][2];                       // [16-frame tile][16-channel tile]
@@ -509,16 +558,16 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
   const int64_t a_row_bytes = (p.a_pitch ? p.a_pitch : p.ldsbx) * 4;
   const int kbt = p.a_pitch ? (p.ktap >> 5) : (p.Kpad >> 5);
   const int64_t tap_bytes = p.a_pitch ? p.tap_stride * 4 : 0;
-  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(m0 + lrow) * a_row_bytes;
+  const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(XV_TLAB_M0(m0) + lrow) * a_row_bytes;
   const int64_t nkb4k = (int64_t)(p.Kpad >> 5) * 4096;
-  const char* Wg = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((n0 >> 5) + wave) * nkb4k + lane * 16;
+  const char* Wg = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((XV_TLAB_N0(n0) >> 5) + wave) * nkb4k + lane * 16;
   const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr_t)As;
 
   auto dma_a = [&](int64_t koff, int buf, int g) {
     const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
     const char* src = Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * DA_BYTES + g * 1024);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" XV_TLAB_ANT ::"v"(src), "s"(dst) : "memory");
   };
   auto dma_slab = [&](int64_t koff, int buf) {      // the 16 eight-row groups of a slab: four per wave
 #pragma unroll
@@ -618,16 +667,16 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
 template <int EPI = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w1p3_kernel(GemmArgs p, int nMt, int nNt) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
-  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
-  const int mt = tile / nNt, nt = tile - mt * nNt;
+  int mt, nt;
+  tile_of_block(blockIdx.x, nMt, nNt, mt, nt);
   w1p3_tile<EPI, F16>(p, mt * BM, nt * BN, smem3);
 }
 
 template <int NPS, int EPI = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_kernel(GemmArgs p, int nMt, int nNt, int w) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
-  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
-  const int mt = tile / nNt, nt = tile - mt * nNt;
+  int mt, nt;
+  tile_of_block(blockIdx.x, nMt, nNt, mt, nt);
   w14p2_tile<NPS, EPI, F16>(p, mt * BM, nt * BN, w, smem3, 0, (p.Kpad >> 5) / w);
 }
 
