@@ -195,12 +195,41 @@ def test_three_slab_kernel_is_bit_identical_to_the_two_slab_kernel(net):
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     for prec in ("bf16x3", "f16x3"):
         tr = _trainer(params, weights, dim, prec)
+        tr.set_option("grid_compact", 0)        # the compact grid form exists on the three-slab kernel only
         a = _run_nodes(tr, feats, offs, nodes)
         tr.set_option("slab3", 0)
         b = _run_nodes(tr, feats, offs, nodes)
         tr.close()
         for node in nodes:
             assert np.array_equal(a[node], b[node]), (net, prec, node)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(resnet_time_stride=True), dict(resnet_maxpooling=True, resnet_time_stride=True)])
+def test_compact_grid_rows_are_bit_identical_to_the_full_enumeration(kw):
+    """ResNet grid convolutions enumerate only their output bins by default (GemmArgs::arow, csrc/grid.hip: no MFMA work on
+    border positions, border zeroed by grid_zero_border_kernel).  Every bin accumulates the same products in the same order
+    as in the full enumeration of the input positions (xv_set_option "grid_compact" 0), so every block output must be
+    bit-identical -- on a ragged batch with even and odd lengths, with and without the time stride.  Run twice on the same
+    workspace: a border left dirty by the first forward would change the second."""
+    from tf_kaldi_speaker_amd import synth
+    import torch
+    params = dict(synth.RESNET_PARAMS, **kw)
+    weights = synth.synth_resnet_weights(params, seed=2)
+    lens = [120, 37, 64, 41, 16, 203]
+    nodes = ("tdnn6_dense", "conv1a", "conv2a", "conv2b_0", "conv3a", "conv4a", "conv4b_0", "conv5_relu")
+    utts = synth.synth_features(len(lens), lens, 40, seed=33)
+    feats = torch.from_numpy(np.concatenate(utts)).cuda()
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    for prec in ("bf16x3", "f16x3"):
+        tr = _trainer(params, weights, 40, prec)
+        a = _run_nodes(tr, feats, offs, nodes)
+        a2 = _run_nodes(tr, feats, offs, nodes)
+        tr.set_option("grid_compact", 0)
+        b = _run_nodes(tr, feats, offs, nodes)
+        tr.close()
+        for node in nodes:
+            assert np.array_equal(a[node], b[node]), (kw, prec, node)
+            assert np.array_equal(a[node], a2[node]), (kw, prec, node, "second forward")
 
 
 def test_f16x3_is_tighter_than_bf16x3_and_reports_overflow():

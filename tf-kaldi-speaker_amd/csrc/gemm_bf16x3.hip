@@ -545,7 +545,7 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
 //   [younger than slab s+1: weights s+1 (4), slab s+2 (4), weights s+2 (4)], then the workgroup barrier (RAW for the slab
 //   read in step s+1; WAR for buffer (s+3) % 3 = s % 3, refilled at the top of step s+1).
 // The loop is unrolled by three, so the slab buffer of a step is a compile-time constant like its weight registers.
-template <int EPI, bool F16>
+template <int EPI, bool F16, bool GATHER = false>
 __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, char* smem3) {
   char* As = smem3;
   const int tid = threadIdx.x;
@@ -563,15 +563,36 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
   const char* Wg = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((XV_TLAB_N0(n0) >> 5) + wave) * nkb4k + lane * 16;
   const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr_t)As;
 
+  // gathered form: this lane's four slab rows (groups wave, 4 + wave, 8 + wave, 12 + wave) start at grid positions
+  // arow[...]; their byte offsets from the operand base (swizzled chunk included: (4 g) & 7 does not depend on i) stay in
+  // four registers and every DMA is base (scalar, advanced with the K block) + offset (vector)
+  uint32_t goff[4] = {0, 0, 0, 0};
+  const char* gbase = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4;
+  if constexpr (GATHER) {
+    const int cg = lpc ^ ((4 * wave + (lrow >> 1)) & 7);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      goff[i] = (uint32_t)p.arow[m0 + lrow + 8 * (4 * i + wave)] * (uint32_t)a_row_bytes + cg * 16;
+  }
   auto dma_a = [&](int64_t koff, int buf, int g) {
     const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
     const char* src = Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * DA_BYTES + g * 1024);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" XV_TLAB_ANT ::"v"(src), "s"(dst) : "memory");
   };
+  auto dma_g = [&](const char* kbase, int buf, int i) {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * DA_BYTES + (4 * i + wave) * 1024);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(goff[i]), "s"(kbase), "s"(dst) : "memory");
+  };
   auto dma_slab = [&](int64_t koff, int buf) {      // the 16 eight-row groups of a slab: four per wave
+    if constexpr (GATHER) {
+      const char* kbase = gbase + koff;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_a(koff, buf, i * 4 + wave);
+      for (int i = 0; i < 4; ++i) dma_g(kbase, buf, i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_a(koff, buf, i * 4 + wave);
+    }
   };
 
   f32x4 acc[8][2];                       // [16-frame tile][16-channel tile]
@@ -664,12 +685,12 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
   stamp(3);
 }
 
-template <int EPI = 0, bool F16 = false>
+template <int EPI = 0, bool F16 = false, bool GATHER = false>
 __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w1p3_kernel(GemmArgs p, int nMt, int nNt) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   int mt, nt;
   tile_of_block(blockIdx.x, nMt, nNt, mt, nt);
-  w1p3_tile<EPI, F16>(p, mt * BM, nt * BN, smem3);
+  w1p3_tile<EPI, F16, GATHER>(p, mt * BM, nt * BN, smem3);
 }
 
 template <int NPS, int EPI = 0, bool F16 = false>
@@ -819,7 +840,8 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
       const void* kernels3[] = {
           reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, false>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, true>),
           reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<1, false>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<1, true>),
-          reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<2, false>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<2, true>)};
+          reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<2, false>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<2, true>),
+          reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, false, true>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, true, true>)};
       for (const void* k : kernels3) {
         r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw1p3);
         if (r != hipSuccess) return r;
@@ -885,6 +907,12 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
 #ifdef XV_GEMM_TRACE
   if (a.trace) g_trace_wgs = (int)grid.x <= kTraceWgs ? (int)grid.x : 0;
 #endif
+  if (a.arow) {                                 // gathered grid rows (ResNet convolutions without border rows)
+    if (w != 1 || tail || !a.a_pitch || a.pool_part) return hipErrorInvalidValue;
+    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, true, true>), grid, block, smemw1p3, s, a, nMain, nNt);
+    else       hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, false, true>), grid, block, smemw1p3, s, a, nMain, nNt);
+    return hipGetLastError();
+  }
   if (w == 1 && !tail && a.slab3) {             // one tap: three slab buffers, slabs two steps ahead
     if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, true>), grid, block, smemw1p3, s, a, nMain, nNt);
     else       hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, false>), grid, block, smemw1p3, s, a, nMain, nNt);

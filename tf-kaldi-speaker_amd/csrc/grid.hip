@@ -10,6 +10,12 @@
 // positions of its INPUT (all of them, border included); rows that do not produce an output bin land on border
 // positions of the output, and their row-map entry says "write zeros there" (xv_epilogue.h out_row): the border
 // is re-zeroed by the epilogue, not by a memset of the whole value.
+//
+// Compact form (split-precision path, default): the GEMM rows enumerate only the OUTPUT BINS of a layer; row m reads its
+// window through a second index (GemmArgs::arow: grid position of the window's top-left corner) and no MFMA work is
+// spent on border rows -- 1 / (F + 1) of the positions, 17 % in stage 4 -- nor, under resnet_time_stride, on the input
+// rows between two output frames.  The border of the output is then zeroed by grid_zero_border_kernel, which writes
+// the border positions only.
 #include "xv_epilogue.h"
 
 namespace xv {
@@ -60,6 +66,80 @@ __global__ void rowmap_grid_ts_kernel(const int32_t* __restrict__ off_in, const 
   const int to = (t - first) >> 1;
   const bool valid = t >= first && ((t - first) & 1) == 0 && to < Lout && j < Fout;
   rowmap[m] = valid ? (int32_t)((int64_t)(off_out[b] + 2 * b) * So + (int64_t)(to + 1) * So + j + 1) : -1;
+}
+
+// utterance whose block [off[b] * unit, off[b + 1] * unit) contains r (no border rows in this enumeration)
+__device__ __forceinline__ int find_utt0(const int32_t* off, int B, int64_t unit, int64_t r) {
+  int lo = 0, hi = B - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int64_t)off[mid] * unit <= r) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// Compact enumeration: GEMM row m = (utterance b, output frame t_o, output bin f_o).  arow[m] = input grid position
+// (pitch Sin) of the top-left corner of the window, rowmap[m] = output grid position (pitch So) of the bin.
+//   frequency: stride 1 -> padded column f_o;  stride 2 (Fin even: TF 'same' pads (0, 1)) -> 2 f_o + 1 for the 3x3 window,
+//              2 f_o for the 1x1 shortcut (whose A operand is offset to the window centre, a_off = (Sin + 1) * cin)
+//   time:      stride 1 -> padded row t_o;  stride 2 -> 2 t_o + first, first as in rowmap_grid_ts_kernel below
+// Entries M .. Mpad - 1 of arow are position 0 (a tile always stages 128 rows).
+__global__ void rowmap_grid_compact_kernel(const int32_t* __restrict__ off_in, const int32_t* __restrict__ off_out, int B,
+                                           int Sin, int So, int Fout, int sw, int st, int ktime,
+                                           int32_t* __restrict__ arow, int32_t* __restrict__ rowmap, int64_t M, int64_t Mpad) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= Mpad) return;
+  if (m >= M) { arow[m] = 0; return; }
+  const int b = find_utt0(off_out, B, Fout, m);
+  const int64_t local = m - (int64_t)off_out[b] * Fout;
+  const int to = (int)(local / Fout), fo = (int)(local - (int64_t)to * Fout);
+  const int Lin = off_in[b + 1] - off_in[b];
+  const int first = (st == 2 && ktime == 3 && (Lin & 1) == 0) ? 1 : 0;
+  const int trow = st == 2 ? 2 * to + first : to;
+  const int col = sw == 2 ? 2 * fo + (ktime == 3 ? 1 : 0) : fo;
+  arow[m] = (int32_t)((int64_t)(off_in[b] + 2 * b) * Sin + (int64_t)trow * Sin + col);
+  rowmap[m] = (int32_t)((int64_t)(off_out[b] + 2 * b) * So + (int64_t)(to + 1) * So + fo + 1);
+}
+
+// Zero the border positions of a grid value (pitch S, F bins; utterance b: top row, L_b x (S - F) side positions, bottom
+// row) and the S positions behind its last row (with the shared border column the window of the last bin of the last
+// utterance ends one position behind the grid).  One thread per (border position, 16-byte chunk); `y` (fp32 rows of
+// chunks_y chunks) and / or `ysb` (split-blocked rows of chunks_sb chunks) may be null.
+__global__ void grid_zero_border_kernel(const int32_t* __restrict__ off0, int B, int F, int S, int chunks_y, int chunks_sb,
+                                        char* __restrict__ y, char* __restrict__ ysb, int64_t nborder) {
+  const int side = S - F;
+  const int cmax = chunks_y > chunks_sb ? chunks_y : chunks_sb;
+  const int64_t total = nborder * cmax;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i / cmax;
+    const int c = (int)(i - k * cmax);
+    const int64_t end = (int64_t)off0[B] * side + (int64_t)2 * S * B;      // border positions inside the grid
+    int64_t pos;
+    if (k >= end) {
+      pos = (int64_t)(off0[B] + 2 * B) * S + (k - end);
+    } else {
+      int lo = 0, hi = B - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int64_t)off0[mid] * side + (int64_t)2 * S * mid <= k) lo = mid; else hi = mid - 1;
+      }
+      const int b = lo, L = off0[b + 1] - off0[b];
+      const int64_t local = k - ((int64_t)off0[b] * side + (int64_t)2 * S * b);
+      const int64_t base = (int64_t)(off0[b] + 2 * b) * S;
+      if (local < S) {
+        pos = base + local;
+      } else if (local < S + (int64_t)L * side) {
+        const int64_t q = local - S;
+        const int t = (int)(q / side), e = (int)(q - (int64_t)t * side);
+        pos = base + (int64_t)(t + 1) * S + (e == 0 ? 0 : S - 1);
+      } else {
+        pos = base + (int64_t)(L + 1) * S + (local - S - (int64_t)L * side);
+      }
+    }
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (y && c < chunks_y) *reinterpret_cast<f32x4*>(y + (pos * chunks_y + c) * 16) = z;
+    if (ysb && c < chunks_sb) *reinterpret_cast<f32x4*>(ysb + (pos * chunks_sb + c) * 16) = z;
+  }
 }
 
 __global__ void rowmap_rows_kernel(const int32_t* __restrict__ off0, int B, int32_t* __restrict__ rowmap, int64_t M) {
@@ -196,6 +276,26 @@ hipError_t launch_build_rowmap_grid_ts(const int32_t* off_in, const int32_t* off
   if (M <= 0) return hipSuccess;
   hipLaunchKernelGGL(rowmap_grid_ts_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, off_in, off_out, B, rows_per_t,
                      Fout, So, ktime, rowmap, M);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_rowmap_grid_compact(const int32_t* off_in, const int32_t* off_out, int B, int Sin, int So, int Fout,
+                                            int sw, int st, int ktime, int32_t* arow, int32_t* rowmap, int64_t M, int64_t Mpad,
+                                            hipStream_t s) {
+  if (Mpad <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rowmap_grid_compact_kernel, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, s, off_in, off_out, B, Sin,
+                     So, Fout, sw, st, ktime, arow, rowmap, M, Mpad);
+  return hipGetLastError();
+}
+
+hipError_t launch_grid_zero_border(const int32_t* off0, int B, int64_t frames, int F, int S, int chunks_y, int chunks_sb,
+                                   float* y, void* ysb, hipStream_t s) {
+  const int64_t nborder = frames * (S - F) + (int64_t)2 * S * B + S;
+  const int cmax = chunks_y > chunks_sb ? chunks_y : chunks_sb;
+  if ((!y && !ysb) || nborder * cmax <= 0) return hipSuccess;
+  const int64_t blocks = (nborder * cmax + 255) / 256;
+  hipLaunchKernelGGL(grid_zero_border_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, off0, B, F, S,
+                     y ? chunks_y : 0, ysb ? chunks_sb : 0, reinterpret_cast<char*>(y), static_cast<char*>(ysb), nborder);
   return hipGetLastError();
 }
 

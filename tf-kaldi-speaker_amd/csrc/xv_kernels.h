@@ -72,6 +72,11 @@ struct GemmArgs {
   int64_t tap_stride;
   int ntaps;              // K == ntaps * ktap
   int ktap;
+  // Gathered grid form (bf16x3 one-tap kernel only): GEMM row m reads the A row that starts at grid position arow[m]
+  // (units of a_pitch elements) instead of position m, so the rows can enumerate just the output bins of a layer --
+  // no MFMA work on border positions (csrc/grid.hip, rowmap_grid_compact_kernel).  arow is padded to a multiple of
+  // 128 rows with position 0.
+  const int32_t* arow;
   // residual shortcut added before the activation (resnet.py:84-85,147-148): fp32 [rows, N]
   const float* R;
   int64_t ldr;
@@ -147,6 +152,13 @@ hipError_t launch_build_rowmap_grid(const int32_t* off0, int B, int rows_per_t, 
 hipError_t launch_build_rowmap_grid_ts(const int32_t* off_in, const int32_t* off_out, int B, int rows_per_t, int Fout, int So,
                                        int ktime, int32_t* rowmap, int64_t M, hipStream_t s);
 // rowmap of conv5 (1 x F valid): rows enumerate padded time rows; valid iff 1 <= t' <= L_b -> frame off0[b]+t'-1
+// compact enumeration of a grid convolution (rows = output bins only): arow[m] = window position, rowmap[m] = output position
+hipError_t launch_build_rowmap_grid_compact(const int32_t* off_in, const int32_t* off_out, int B, int Sin, int So, int Fout,
+                                            int sw, int st, int ktime, int32_t* arow, int32_t* rowmap, int64_t M, int64_t Mpad,
+                                            hipStream_t s);
+// zero the border positions (and one pitch behind the last row) of a grid value; chunks = 16-byte chunks per position
+hipError_t launch_grid_zero_border(const int32_t* off0, int B, int64_t frames, int F, int S, int chunks_y, int chunks_sb,
+                                   float* y, void* ysb, hipStream_t s);
 hipError_t launch_build_rowmap_rows(const int32_t* off0, int B, int32_t* rowmap, int64_t M, hipStream_t s);
 // rowmap of conv0 (rows = grid positions, pitch S): interior -> same position, border -> zeros at the same position
 hipError_t launch_build_rowmap_interior(const int32_t* off0, int B, int F, int S, int32_t* rowmap, int64_t M, hipStream_t s);

@@ -146,6 +146,7 @@ struct xv_handle {
   int opt_pool_fusion = 1;                            // statistics pooling fused into the last frame layer's epilogue
   int opt_tail_split = 1;                             // K-split of the last, nearly empty round of GEMM tiles
   int opt_slab3 = 1;                                  // one-tap GEMM layers on the three-slab-buffer kernel
+  int opt_grid_compact = 1;                           // ResNet grid convolutions enumerate output bins only (split precisions)
   int opt_att_fusion = 1;                             // attention scores / weighted moments in the GEMM epilogues
   int opt_profile_dominant = 0;                       // xv_profile_*: bracket only the step with the most FLOPs of a plan
   // device index arrays of destroyed plans, kept for the next plan (no hipMalloc / hipFree per ragged batch)
@@ -195,6 +196,8 @@ struct PlanStep {
   int lvl_in = 0, lvl_out = 0;  // time level of the input / output value
   int64_t frames_out = 0;       // total frames of the batch at the output's time level
   bool grid_cover = false;      // grid-valued output whose border is re-zeroed by zero-writing GEMM rows (no memset)
+  bool compact = false;         // grid convolution whose GEMM rows are the output bins only (csrc/grid.hip, compact form)
+  int arow = -1;                // compact: index into plan rowmaps of the window positions (GemmArgs::arow)
   int fuse_att = 0;             // GEMM: 1 = score partials instead of the key, 2 = weighted moments instead of the value;
                                 // ATT_SCORES / ATT_SOFTMAX / ATT_POOL: 1 = the fused form of that op
   int64_t att_w_off = -1;       // fuse_att 2: workspace offset of the softmax output (weights [rows, H])
@@ -888,6 +891,7 @@ int xv_set_option(xv_handle* h, const char* name, int value) {
   else if (!strcmp(name, "tail_split")) h->opt_tail_split = value != 0;
   else if (!strcmp(name, "att_fusion")) h->opt_att_fusion = value != 0;
   else if (!strcmp(name, "slab3")) h->opt_slab3 = value != 0;
+  else if (!strcmp(name, "grid_compact")) h->opt_grid_compact = value != 0;
   else if (!strcmp(name, "profile_dominant")) h->opt_profile_dominant = value != 0;
   else return fail(h, XV_ERR_INVALID, "xv_set_option: unknown option '%s'", name);
   return XV_OK;
@@ -1110,17 +1114,28 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       st.stage = st.to_out ? node.stage : L.final_stage();
       const int64_t padded_rows = Fl[st.lvl_in] + 2 * (int64_t)batch;   // input time rows incl. the two border rows per utterance
       if (L.mode == 0) st.M = (int)(st.rows_in - (L.w - 1));
+      else if ((L.mode == 1 || L.mode == 2) && L.use_split && h->opt_grid_compact &&
+               st.rows_in * (int64_t)sb_ld(L.cin) * 4 < ((int64_t)1 << 32)) {
+        st.compact = true;                 // rows = output bins; 32-bit byte offsets of the window positions
+        st.M = (int)(Fl[st.lvl_out] * L.Fout);
+      }
       else if (L.mode == 1 || L.mode == 2) st.M = (int)(padded_rows * (h->values[op.in0].grid_S / L.sw));
       else if (L.mode == 3) st.M = (int)padded_rows;
       else st.M = (int)(padded_rows * h->values[op.out].grid_S);     // conv0: one row per output grid position
       // does every border position of the output get a zero-writing GEMM row? (csrc/grid.hip)  If not the value is
       // zeroed as a whole before the layer runs.
-      if (L.mode == 1 || L.mode == 2) st.grid_cover = L.st == 1 && h->values[op.in0].grid_S / L.sw == h->values[op.out].grid_S;
+      if (st.compact) st.grid_cover = false;
+      else if (L.mode == 1 || L.mode == 2) st.grid_cover = L.st == 1 && h->values[op.in0].grid_S / L.sw == h->values[op.out].grid_S;
       else if (L.mode == 4) st.grid_cover = true;
       if (L.w > 1 || L.mode != 0) {
         st.rowmap = (int)p->rowmap_off.size();
         p->rowmap_off.push_back(rowmap_elems);
         rowmap_elems += align_up(st.M, 64);
+        if (st.compact) {
+          st.arow = (int)p->rowmap_off.size();
+          p->rowmap_off.push_back(rowmap_elems);
+          rowmap_elems += align_up(st.M, 128);
+        }
       }
       const int64_t valid_out = L.mode == 0 ? st.rows_out : Fl[st.lvl_out] * (L.mode == 3 ? 1 : L.Fout);
       st.flops = 2 * valid_out * (int64_t)L.cout * L.K();
@@ -1292,6 +1307,11 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       const int32_t* doff = p->dev_offsets(st.lvl_in);
       int32_t* rm = static_cast<int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.rowmap];
       if (L.mode == 0) e = launch_build_rowmap(doff, batch, ctx_in, L.w, rm, st.M, s);
+      else if (st.compact)
+        e = launch_build_rowmap_grid_compact(doff, p->dev_offsets(st.lvl_out), batch, h->values[op.in0].grid_S,
+                                             h->values[op.out].grid_S, L.Fout, L.sw, L.st, L.mode == 1 ? 3 : 1,
+                                             static_cast<int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.arow], rm, st.M,
+                                             align_up(st.M, 128), s);
       else if ((L.mode == 1 || L.mode == 2) && L.st == 2)
         e = launch_build_rowmap_grid_ts(doff, p->dev_offsets(st.lvl_out), batch, h->values[op.in0].grid_S / L.sw, L.Fout,
                                         h->values[op.out].grid_S, L.mode == 1 ? 3 : 1, rm, st.M, s);
@@ -1438,7 +1458,11 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           // (whole-value clear: one more time row than the value has -- with the shared border column the 3x3 window of
           // the last bin of the last utterance's bottom border row reads position (L + 2, 0), just behind the grid)
           const size_t rows0 = st.grid_cover && L.mode != 4 ? head : (st.grid_cover ? 0 : (size_t)st.rows_out + vo.grid_S);
-          if (rows0 > 0) {
+          if (st.compact) {                 // border positions only
+            XV_HIP(h, launch_grid_zero_border(p->dev_offsets(st.lvl_out), B, st.frames_out, vo.grid_F, vo.grid_S, L.cout / 4,
+                                              sb_ld(L.cout) / 4, st.out_off >= 0 ? reinterpret_cast<float*>(ws + st.out_off) : nullptr,
+                                              st.out_sb_off >= 0 ? ws + st.out_sb_off : nullptr, s));
+          } else if (rows0 > 0) {
             if (st.out_off >= 0) XV_HIP(h, hipMemsetAsync(ws + st.out_off, 0, rows0 * L.cout * 4, s));
             if (st.out_sb_off >= 0) XV_HIP(h, hipMemsetAsync(ws + st.out_sb_off, 0, rows0 * sb_ld(L.cout) * 4, s));
           }
@@ -1447,6 +1471,11 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           const int64_t Sin = h->values[op.in0].grid_S;
           a.a_pitch = (L.mode == 3 ? Sin : L.sw) * (int64_t)L.cin;
           a.a_off = L.mode == 1 ? (L.sw == 1 ? 0 : L.cin) : (L.mode == 2 ? (Sin + 1) * L.cin : L.cin);
+          if (st.compact) {                 // rows address their window through arow (units of one grid position)
+            a.arow = static_cast<const int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.arow];
+            a.a_pitch = L.cin;
+            a.a_off = L.mode == 1 ? 0 : (Sin + 1) * L.cin;
+          }
           a.ntaps = L.mode == 1 ? 3 : 1;
           a.ktap = L.mode == 1 ? 3 * L.cin : (L.mode == 2 ? L.cin : L.Fin * L.cin);
           a.tap_stride = Sin * L.cin;
