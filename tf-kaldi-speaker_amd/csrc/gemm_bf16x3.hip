@@ -522,7 +522,10 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
     if (s + 1 < nsteps) step(s + 1, W1, W0);
     if (s + 2 < nsteps) step(s + 2, W2, W1);
   }
+  // every wave's last (dummy) slab pieces have landed before any wave turns the slab buffers into its epilogue scratch:
+  // the waves of a workgroup can be a step apart here, and a piece issued at the top of that step may still be in flight
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   __builtin_amdgcn_sched_barrier(0);
   stamp(2);
   // the epilogue's per-lane addresses all derive from the lane id: made opaque here, they cannot be hoisted above the K
@@ -560,7 +563,14 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
   const int64_t tap_bytes = p.a_pitch ? p.tap_stride * 4 : 0;
   const char* Ag = reinterpret_cast<const char*>(p.Xsb) + p.a_off * 4 + (int64_t)(XV_TLAB_M0(m0) + lrow) * a_row_bytes;
   const int64_t nkb4k = (int64_t)(p.Kpad >> 5) * 4096;
-  const char* Wg = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((XV_TLAB_N0(n0) >> 5) + wave) * nkb4k + lane * 16;
+  // Channel-block role of this wave.  A layer narrower than the tile (ResNet stage 1: 64 channels in a 128-channel tile)
+  // leaves two of the four blocks pure padding: the waves that own them only stage their share of the slabs and keep the
+  // barriers (no weight loads, no MFMAs, no epilogue), and WHICH waves those are alternates with the workgroup's dispatch
+  // slot, so that the computing waves of the workgroups sharing a CU do not all sit on the same two SIMDs.
+  const bool narrow = EPI == 0 && p.N <= 64 && !p.pool_part && !p.raw;
+  const int wv = narrow ? (wave ^ (((blockIdx.x >> 8) & 1) << 1)) : wave;
+  const bool passive = narrow && n0 + wv * 32 >= p.N;
+  const char* Wg = reinterpret_cast<const char*>(p.Wfr) + (int64_t)((XV_TLAB_N0(n0) >> 5) + wv) * nkb4k + lane * 16;
   const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr_t)As;
 
   // gathered form: this lane's four slab rows (groups wave, 4 + wave, 8 + wave, 12 + wave) start at grid positions
@@ -619,6 +629,24 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
       koff_issue += 128;
     }
   };
+  if (passive) {                          // uniform per wave: slabs and barriers only (see `narrow` above)
+    dma_slab(0, 0);
+    advance();
+    dma_slab(1 < nsteps ? koff_issue : 0, 1);
+    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0, buf = 2; s < nsteps; ++s) {
+      dma_slab(s + 2 < nsteps ? koff_issue : 0, buf);        // slab s + 2 into buffer (s + 2) % 3
+      buf = buf == 2 ? 0 : buf + 1;
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // this wave's pieces of slab s + 1 have landed
+      __syncthreads();
+      advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                      // the barrier in front of the other waves' epilogue (below)
+    return;
+  }
   bf16x8 W0[4], W1[4], W2[4];            // [plane * 2 + channel tile]; W0: step 0, W1: step 1
   {
     const char* q0 = Wg;
@@ -673,7 +701,10 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
     if (s + 1 < nsteps) step(s + 1, 1, W1, W0);
     if (s + 2 < nsteps) step(s + 2, 2, W2, W1);
   }
+  // every wave's last (dummy) slab pieces have landed before any wave turns the slab buffers into its epilogue scratch:
+  // the waves of a workgroup can be a step apart here, and a piece issued at the top of that step may still be in flight
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   __builtin_amdgcn_sched_barrier(0);
   stamp(2);
   // the epilogue's per-lane addresses all derive from the lane id: made opaque here, they cannot be hoisted above the K
@@ -681,7 +712,7 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
-  else store_wave_tile_n32<64, F16>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
+  else store_wave_tile_n32<64, F16>(p, acc, m0, n0 + wv * 32, lane_e, wave, smem3);
   stamp(3);
 }
 
