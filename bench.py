@@ -9,8 +9,9 @@ scaling, no collective on the data path; torch.distributed is used for the timin
 and the max-over-ranks only).
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  `value` is the config-2 rate above; beside it
-  roofline     : dominant kernel (tdnn3_conv GEMM), algorithmic FLOPs / hipEvent-measured
-                 mean launch duration inside the timed region, against the dense MFMA peak;
+  roofline     : dominant kernel (tdnn3_conv GEMM), algorithmic FLOPs / hipEvent-measured mean launch duration
+                 over a second pass of the same K steps (the events cost 6-9 % of a step, so the region `value`
+                 is taken from carries none), against the dense MFMA peak;
   cpu_baseline : the CPU stand-in of the reference's extraction job (oracle/cpu_extract.py: ark -> ark,
                  1 thread, batch 1) run as nj = min(host cores, 32) fresh processes side by side
                  (run_extract_embeddings.sh:3,68) for a bounded time; N = 1 only;
@@ -337,21 +338,14 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_dev()
-    # Bracketing all 14 launches of a step with hipEvents costs ~4 % of the step, so inside the region `value` comes
-    # from only the dominant layer (most FLOPs: tdnn3_conv) is bracketed; its interval there also covers the launch gaps
-    # and the drain of the previous layer (the marker is consumed while that layer is still finishing), so it reads
-    # ~8 % longer than the layer takes.  `roofline` and the per-kernel table therefore come from a SECOND timed region
-    # of the same K steps in which every launch is bracketed (consistent with the rocprofv3 trace in profiles/); the
-    # first region's reading is kept as roofline.launch_ms_value_region.
-    if not args.no_profile:
-        tr.set_option("profile_dominant", 1)
-        tr.profile_begin(max_events=2 * (args.steps + 1))
+    # `value` comes from a region WITHOUT hipEvents: an event pair around even one layer keeps the next kernel from
+    # starting while the previous one drains (bracketing only tdnn3_conv cost 5.8 % of the step, all 14 launches ~9 %).
+    # `roofline` and the per-kernel table come from a SECOND timed region of the same K steps in which every launch is
+    # bracketed (its per-kernel averages agree with the rocprofv3 trace in profiles/).
     # barrier + synchronize, exactly K steps, barrier + synchronize, max over ranks
     elapsed = sharding.timed_steps(step, args.steps, sync_dev, dist=d, device=red_dev)
-    kernels, dominant = [], []
+    kernels = []
     if not args.no_profile:
-        dominant, _ = tr.profile_end()
-        tr.set_option("profile_dominant", 0)
         tr.profile_begin(max_events=2 * 48 * (args.steps + 1))
         sharding.timed_steps(step, args.steps, sync_dev, dist=d, device=red_dev)
         kernels, _ = tr.profile_end()
@@ -407,8 +401,6 @@ def main():
                     "launch_ms": round(dom["ms"], 4),
                     "hbm_frac_algorithmic": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             roof["algorithmic_bytes"] = dom["bytes"]
-            if dominant and dominant[0]["name"] == dom["name"]:
-                roof["launch_ms_value_region"] = round(dominant[0]["ms"], 4)
             if precision != "f32":
                 roof["mfma_issue_frac"] = round(3 * tf / peak, 4)
                 roof["note"] = ("split precision: 3 MFMAs per algorithmic product, so the ceiling of `frac` is 1/3; "

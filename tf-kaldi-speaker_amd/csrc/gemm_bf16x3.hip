@@ -724,36 +724,39 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w1p3_kernel(GemmArgs p, in
   w1p3_tile<EPI, F16, GATHER>(p, mt * BM, nt * BN, smem3);
 }
 
-template <int NPS, int EPI = 0, bool F16 = false>
-__global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_kernel(GemmArgs p, int nMt, int nNt, int w) {
-  extern __shared__ __attribute__((aligned(16))) char smem3[];
-  int mt, nt;
-  tile_of_block(blockIdx.x, nMt, nNt, mt, nt);
-  w14p2_tile<NPS, EPI, F16>(p, mt * BM, nt * BN, w, smem3, 0, (p.Kpad >> 5) / w);
-}
-
-// K-split form for the M tiles of the last, nearly empty round (gemm_bf16x3_tail_plan): workgroup = (tile, slice);
+// Workgroups [0, nMt * nNt) are whole tiles.  With S > 0 the grid continues with the K-split slices of the tail tiles
+// (gemm_bf16x3_tail_plan: the M tiles nMt .. nMt + tail_mt - 1 of the last, nearly empty round): workgroup = (tile, slice),
 // slice s accumulates channel blocks [s * ncb / S, (s + 1) * ncb / S) and stores its RAW accumulators to
-// partial[s][row - mt0 * 128][Npad]; bf16x3_tail_reduce_kernel adds the slices in order and runs the epilogue.
-template <int NPS, bool F16 = false>
-__global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_tail_kernel(GemmArgs p, int mt0, int nNt, int w, int S) {
+// partial[s][row - nMt * 128][Npad]; bf16x3_tail_reduce_kernel adds the slices in order and runs the epilogue.  The slices
+// are the highest workgroup ids, so they are dispatched into the slots the last whole tiles leave free -- as their own
+// launch they ran latency-bound on an otherwise idle chip (17-21 us per layer for 1.4 % of its MFMA work).
+template <int NPS, int EPI = 0, bool F16 = false>
+__global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_kernel(GemmArgs p, int nMt, int nNt, int w, int S) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
-  const int split = blockIdx.x % S, tile = blockIdx.x / S;
-  const int mt = mt0 + tile / nNt, nt = tile % nNt;
-  const int ncb = (p.Kpad >> 5) / w, per = ncb / S;
-  GemmArgs q = p;
-  q.raw = 1;
-  q.act = ACT_NONE;                      // raw partial sums: no scale / shift / activation before the reduce
-  q.alpha = nullptr;
-  q.Y = p.partial + ((int64_t)split * p.tail_mt - mt0) * (int64_t)BM * p.Npad;   // row m of the tile -> slice row m - mt0*128
-  q.ldy = p.Npad;
-  q.N = p.Npad;
-  q.M = (mt0 + p.tail_mt) * BM;          // every row of the tail tiles is stored (rows >= M are never read back)
-  q.Ysb = nullptr;
-  q.rowmap = nullptr;
-  q.R = nullptr;
-  q.pool_part = nullptr;
-  w14p2_tile<NPS, 0, F16>(q, mt * BM, nt * BN, w, smem3, split * per, (split + 1) * per);
+  int mt, nt, cb_begin = 0, cb_end = (p.Kpad >> 5) / w;
+  if (EPI == 0 && (int)blockIdx.x >= nMt * nNt) {
+    const int id = blockIdx.x - nMt * nNt;
+    const int split = id % S, tile = id / S;
+    mt = nMt + tile / nNt;
+    nt = tile % nNt;
+    const int per = cb_end / S;
+    cb_begin = split * per;
+    cb_end = cb_begin + per;
+    p.Y = p.partial + ((int64_t)split * p.tail_mt - nMt) * (int64_t)BM * p.Npad;   // row m of the tile -> slice row m - nMt*128
+    p.raw = 1;
+    p.act = ACT_NONE;                    // raw partial sums: no scale / shift / activation before the reduce
+    p.alpha = nullptr;
+    p.ldy = p.Npad;
+    p.N = p.Npad;
+    p.M = (nMt + p.tail_mt) * BM;        // every row of the tail tiles is stored (rows >= M are never read back)
+    p.Ysb = nullptr;
+    p.rowmap = nullptr;
+    p.R = nullptr;
+    p.pool_part = nullptr;
+  } else {
+    tile_of_block(blockIdx.x, nMt, nNt, mt, nt);
+  }
+  w14p2_tile<NPS, EPI, F16>(p, mt * BM, nt * BN, w, smem3, cb_begin, cb_end);
 }
 
 // one thread per (tail row, 4 channels): ordered sum of the K slices, then the usual epilogue (BN scale/shift,
@@ -859,10 +862,9 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
       const void* kernels[] = {
           reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1, 0, false>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 0, false>),
           reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 1, false>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 2, false>),
-          reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<1, false>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<4, false>),
           reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1, 0, true>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 0, true>),
           reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 1, true>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 2, true>),
-          reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<1, true>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_tail_kernel<4, true>)};
+};
       hipError_t r = hipSuccess;
       for (const void* k : kernels) {
         r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
@@ -914,11 +916,11 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
     const dim3 grid(nMt * nNt);
     if (!a.slab3) {
       if (a.att_part) {
-        if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 1, true>), grid, block, smemw32, s, a, nMt, nNt, w);
-        else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 1, false>), grid, block, smemw32, s, a, nMt, nNt, w);
+        if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 1, true>), grid, block, smemw32, s, a, nMt, nNt, w, 0);
+        else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 1, false>), grid, block, smemw32, s, a, nMt, nNt, w, 0);
       } else {
-        if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 2, true>), grid, block, smemw32, s, a, nMt, nNt, w);
-        else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 2, false>), grid, block, smemw32, s, a, nMt, nNt, w);
+        if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 2, true>), grid, block, smemw32, s, a, nMt, nNt, w, 0);
+        else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 2, false>), grid, block, smemw32, s, a, nMt, nNt, w, 0);
       }
       return hipGetLastError();
     }
@@ -949,25 +951,18 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
     else       hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, false>), grid, block, smemw1p3, s, a, nMain, nNt);
     return hipGetLastError();
   }
+  // whole tiles, then (tail form) the K-split slices of the tail tiles in the same launch
+  const int S = tail ? a.ksplit : 0;
+  const dim3 grid2(nMain * nNt + (tail ? a.tail_mt * nNt * a.ksplit : 0));
   if (w >= 5) {
-    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 0, true>), grid, block, smemw32, s, a, nMain, nNt, w);
-    else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 0, false>), grid, block, smemw32, s, a, nMain, nNt, w);
+    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 0, true>), grid2, block, smemw32, s, a, nMain, nNt, w, S);
+    else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 0, false>), grid2, block, smemw32, s, a, nMain, nNt, w, S);
   } else {
-    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 0, true>), grid, block, smemw32, s, a, nMain, nNt, w);
-    else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 0, false>), grid, block, smemw32, s, a, nMain, nNt, w);
+    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 0, true>), grid2, block, smemw32, s, a, nMain, nNt, w, S);
+    else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 0, false>), grid2, block, smemw32, s, a, nMain, nNt, w, S);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || !tail) return e;
-  const dim3 tgrid(a.tail_mt * nNt * a.ksplit);
-  if (w >= 5) {
-    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<1, true>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
-    else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<1, false>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
-  } else {
-    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<4, true>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
-    else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_tail_kernel<4, false>), tgrid, block, smemw32, s, a, nMain, nNt, w, a.ksplit);
-  }
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
   const int64_t total = (int64_t)a.tail_mt * BM * (a.Npad >> 2);
   hipLaunchKernelGGL(bf16x3_tail_reduce_kernel, dim3((unsigned)((total + 255) / 256)), block, 0, s, a, nMain, a.ksplit);
   return hipGetLastError();
