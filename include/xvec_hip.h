@@ -256,6 +256,10 @@ int xv_ark_next_batch(xv_ark_reader* r, int64_t max_frames, int max_utts, int mi
  * "a single utterance does not fit ..."): lets the caller retry with a larger buffer.  XV_ERR_STATE if none. */
 int xv_ark_pending_shape(const xv_ark_reader* r, int32_t* rows, int32_t* cols);
 int64_t xv_ark_skipped(const xv_ark_reader* r);
+/* Threads that copy the float payloads of a batch when the ark is a regular file opened by name (the file is mapped for
+ * header parsing and the payloads are pread() straight into `dst`).  Default: 4 on hosts with >= 8 cores, else 2 / 1.
+ * n is clamped to [1, 16].  No reference counterpart (dataset/kaldi_io.py reads one record at a time). */
+int xv_ark_set_copy_threads(xv_ark_reader* r, int n);
 const char* xv_ark_error(const xv_ark_reader* r);
 void xv_ark_close(xv_ark_reader* r);
 /* Format n float vectors (row i = data + i*ld, `dim` values) as binary Kaldi vector records

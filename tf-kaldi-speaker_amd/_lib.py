@@ -26,7 +26,7 @@ EXPORTS = ["xv_version", "xv_create", "xv_set_tensor", "xv_finalize", "xv_set_op
            "xv_plan_create", "xv_plan_query", "xv_plan_destroy", "xv_forward", "xv_profile_begin", "xv_profile_end",
            "xv_destroy", "xv_last_error",
            "xv_frontend_cmn_select", "xv_length_normalize", "xv_speaker_mean",
-           "xv_ark_open", "xv_ark_open_scp", "xv_ark_scp_count", "xv_ark_scp_shapes", "xv_ark_next_batch", "xv_ark_pending_shape", "xv_ark_skipped", "xv_ark_error", "xv_ark_close", "xv_ark_format_vectors"]
+           "xv_ark_open", "xv_ark_open_scp", "xv_ark_scp_count", "xv_ark_scp_shapes", "xv_ark_next_batch", "xv_ark_pending_shape", "xv_ark_skipped", "xv_ark_set_copy_threads", "xv_ark_error", "xv_ark_close", "xv_ark_format_vectors"]
 
 
 class ModelDesc(C.Structure):
@@ -109,6 +109,7 @@ def load():
     lib.xv_ark_next_batch.argtypes = [vp, i64, i32, i32, vp, i64, vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
     lib.xv_ark_pending_shape.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.xv_ark_skipped.argtypes = [vp]
+    lib.xv_ark_set_copy_threads.argtypes = [vp, i32]
     lib.xv_ark_skipped.restype = i64
     lib.xv_ark_error.argtypes = [vp]
     lib.xv_ark_error.restype = C.c_char_p

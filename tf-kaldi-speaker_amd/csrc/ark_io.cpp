@@ -15,9 +15,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/xvec_hip.h"
@@ -25,8 +28,19 @@
 struct xv_ark_reader {
   int fd = -1;
   bool own_fd = false;
-  std::vector<unsigned char> buf;   // read-ahead window
+  std::vector<unsigned char> buf;   // read-ahead window (streams: pipes, descriptors)
+  const unsigned char* win = nullptr;   // base of the bytes [pos, end): buf.data(), or the mapping of a regular file
   size_t pos = 0, end = 0;
+  // a regular file opened by name is mapped: headers are parsed in place (no read() per record, no window to refill) and
+  // the float payloads of a batch go from the page cache into the caller's (pinned) buffer by pread() from a few
+  // threads -- one copy, no page faults on the payload pages of the mapping
+  void* map = nullptr;
+  size_t map_len = 0;
+  // mapped float payloads of the batch being assembled: copied at the end of xv_ark_next_batch, by a few threads
+  struct Copy { int64_t off; float* dst; size_t bytes; };
+  bool copy_failed = false;
+  std::vector<Copy> copies;
+  int copy_threads = 1;
   bool eof = false;
   std::string err;
   // one parsed-but-not-yet-delivered record header (when it did not fit the caller's batch)
@@ -53,8 +67,9 @@ constexpr size_t kChunk = 64u << 10;     // read-ahead window: headers only; flo
 // make sure n bytes are available at r->pos (false at EOF / error)
 bool fill(xv_ark_reader* r, size_t n) {
   if (r->end - r->pos >= n) return true;
+  if (r->map) return false;              // mapped file: [pos, end) is all there is
   if (r->pos > 0) {
-    memmove(r->buf.data(), r->buf.data() + r->pos, r->end - r->pos);
+    memmove(r->buf.data(), r->win + r->pos, r->end - r->pos);
     r->end -= r->pos;
     r->pos = 0;
   }
@@ -71,7 +86,77 @@ bool fill(xv_ark_reader* r, size_t n) {
     r->end += (size_t)got;
     r->file_pos += got;
   }
+  r->win = r->buf.data();
   return r->end - r->pos >= n;
+}
+
+// threads for the payload copies of a mapped ark (a job of the launcher is one process per GPU; 16 host cores per GPU)
+int default_copy_threads() {
+  const unsigned hw = std::thread::hardware_concurrency();
+  return hw >= 8 ? 4 : (hw >= 4 ? 2 : 1);
+}
+
+void unmap_file(xv_ark_reader* r) {
+  if (r->map) munmap(r->map, r->map_len);
+  r->map = nullptr;
+  r->map_len = 0;
+  r->win = r->buf.data();
+}
+
+// map r->fd if it is a non-empty regular file (else the read() path stays in use); `sequential` = whole-ark scan
+void map_file(xv_ark_reader* r, bool sequential) {
+  unmap_file(r);
+  struct stat st;
+  if (fstat(r->fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) return;
+  void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, r->fd, 0);
+  if (m == MAP_FAILED) return;
+  (void)sequential;
+  r->map = m;
+  r->map_len = (size_t)st.st_size;
+  r->win = static_cast<const unsigned char*>(m);
+  r->pos = 0;
+  r->end = r->map_len;
+  r->file_pos = (int64_t)r->map_len;
+  r->eof = true;
+}
+
+// run the noted payload copies: contiguous shares of the byte total per thread (a share may start inside a record)
+void run_copies(xv_ark_reader* r) {
+  std::vector<xv_ark_reader::Copy>& c = r->copies;
+  if (c.empty()) return;
+  size_t total = 0;
+  for (const auto& x : c) total += x.bytes;
+  const int nt = total >= ((size_t)2 << 20) ? r->copy_threads : 1;
+  const int fd = r->fd;
+  bool* failed = &r->copy_failed;
+  auto work = [&c, fd, failed](size_t lo, size_t hi) {     // bytes [lo, hi) of the concatenation of all copies
+    size_t at = 0;
+    for (const auto& x : c) {
+      if (hi <= at) break;
+      size_t a = lo > at ? lo - at : 0;
+      const size_t b = (hi - at < x.bytes) ? hi - at : x.bytes;
+      while (a < b) {
+        const ssize_t got = pread(fd, reinterpret_cast<unsigned char*>(x.dst) + a, b - a, (off_t)(x.off + (int64_t)a));
+        if (got < 0 && errno == EINTR) continue;
+        if (got <= 0) { *failed = true; return; }
+        a += (size_t)got;
+      }
+      at += x.bytes;
+    }
+  };
+  if (nt <= 1) {
+    work(0, total);
+  } else {
+    std::vector<std::thread> th;
+    const size_t share = ((total + nt - 1) / nt + 4095) & ~(size_t)4095;
+    for (int t = 1; t < nt; ++t) {
+      const size_t lo = share * t, hi = lo + share < total ? lo + share : total;
+      if (lo < hi) th.emplace_back(work, lo, hi);
+    }
+    work(0, share < total ? share : total);
+    for (auto& x : th) x.join();
+  }
+  c.clear();
 }
 
 int fail(xv_ark_reader* r, const char* msg) {
@@ -83,7 +168,7 @@ int fail(xv_ark_reader* r, const char* msg) {
 // Float vectors ('FV ' / 'DV ', e.g. per-frame VAD decisions) are delivered as [dim, 1] matrices.
 int parse_matrix_header(xv_ark_reader* r, std::string& key) {
   if (!fill(r, 5)) return fail(r, "unexpected end of stream after the key");
-  const unsigned char* p = r->buf.data() + r->pos;
+  const unsigned char* p = r->win + r->pos;
   if (p[0] != 0 || p[1] != 'B') return fail(r, "text-mode or unknown record (expected \\\\0B)");
   int kind = 0;
   bool vec = false;
@@ -96,7 +181,7 @@ int parse_matrix_header(xv_ark_reader* r, std::string& key) {
   r->pos += 5;
   if (kind == 3) {
     if (!fill(r, 16)) return fail(r, "truncated compressed-matrix header");
-    const unsigned char* q = r->buf.data() + r->pos;
+    const unsigned char* q = r->win + r->pos;
     memcpy(&r->pending_min, q, 4);
     memcpy(&r->pending_range, q + 4, 4);
     memcpy(&r->pending_rows, q + 8, 4);
@@ -104,14 +189,14 @@ int parse_matrix_header(xv_ark_reader* r, std::string& key) {
     r->pos += 16;
   } else if (vec) {
     if (!fill(r, 5)) return fail(r, "truncated vector header");
-    const unsigned char* q = r->buf.data() + r->pos;
+    const unsigned char* q = r->win + r->pos;
     if (q[0] != 4) return fail(r, "vector header: int-size marker missing");
     memcpy(&r->pending_rows, q + 1, 4);
     r->pending_cols = 1;
     r->pos += 5;
   } else {
     if (!fill(r, 10)) return fail(r, "truncated matrix header");
-    const unsigned char* q = r->buf.data() + r->pos;
+    const unsigned char* q = r->win + r->pos;
     if (q[0] != 4 || q[5] != 4) return fail(r, "matrix header: int-size markers missing");
     memcpy(&r->pending_rows, q + 1, 4);
     memcpy(&r->pending_cols, q + 6, 4);
@@ -136,7 +221,7 @@ int parse_header(xv_ark_reader* r) {
       if (blank) return 0;
       return fail(r, "unexpected end of stream inside a key");
     }
-    const unsigned char* p = r->buf.data() + r->pos;
+    const unsigned char* p = r->win + r->pos;
     const size_t avail = r->end - r->pos;
     const void* sp = memchr(p, ' ', avail);
     if (sp) {
@@ -159,6 +244,11 @@ int parse_header(xv_ark_reader* r) {
 
 // scp mode: position the descriptor at `offset` of the current file; bytes already in the read-ahead window are kept
 int seek_to(xv_ark_reader* r, int64_t offset) {
+  if (r->map) {
+    if (offset < 0 || (uint64_t)offset > r->map_len) return fail(r, "scp offset beyond the end of the ark");
+    r->pos = (size_t)offset;
+    return XV_OK;
+  }
   const int64_t cur = r->file_pos - (int64_t)(r->end - r->pos);
   if (offset >= cur && offset <= r->file_pos) {
     r->pos += (size_t)(offset - cur);
@@ -176,6 +266,7 @@ int parse_scp_entry(xv_ark_reader* r) {
   if (r->next_entry >= r->entries.size()) return 0;
   const xv_ark_reader::ScpEntry& e = r->entries[r->next_entry++];
   if (e.path != r->cur_path) {
+    unmap_file(r);
     if (r->fd >= 0) close(r->fd);
     r->fd = open(r->paths[e.path].c_str(), O_RDONLY);
     if (r->fd < 0) {
@@ -186,6 +277,7 @@ int parse_scp_entry(xv_ark_reader* r) {
     r->pos = r->end = 0;
     r->file_pos = 0;
     r->eof = false;
+    map_file(r, false);
   }
   const int rc = seek_to(r, e.offset);
   if (rc < 0) return rc;
@@ -199,15 +291,23 @@ int read_payload(xv_ark_reader* r, float* dst) {
   r->have_pending = false;
   if (r->pending_kind == 1 || r->pending_kind == 2) {
     const size_t es = r->pending_kind == 1 ? 4 : 8;
+    if (es == 4 && dst && r->map) {         // mapped file: note the copy, do it with the rest of the batch
+      const size_t need = (size_t)n * 4;
+      if (r->end - r->pos < need) return fail(r, "truncated matrix payload");
+      r->copies.push_back({(int64_t)r->pos, dst, need});
+      r->pos += need;
+      return XV_OK;
+    }
     if (es == 4 && dst) {
       // float payload: take what the read-ahead window already holds, then read() the rest straight
       // into the destination (one copy instead of two)
       size_t need = (size_t)n * 4, have = r->end - r->pos;
       if (have > need) have = need;
-      memcpy(dst, r->buf.data() + r->pos, have);
+      memcpy(dst, r->win + r->pos, have);
       r->pos += have;
       unsigned char* out = reinterpret_cast<unsigned char*>(dst) + have;
       need -= have;
+      if (need > 0 && r->map) return fail(r, "truncated matrix payload");
       while (need > 0) {
         const ssize_t got = read(r->fd, out, need);
         if (got < 0) {
@@ -226,7 +326,7 @@ int read_payload(xv_ark_reader* r, float* dst) {
     while (left > 0) {                       // stream through the window: a record may exceed it
       const int64_t want = left < (int64_t)(kChunk / es) ? left : (int64_t)(kChunk / es);
       if (!fill(r, (size_t)want * es)) return fail(r, "truncated matrix payload");
-      const unsigned char* q = r->buf.data() + r->pos;
+      const unsigned char* q = r->win + r->pos;
       if (out) {
         if (es == 4) {
           memcpy(out, q, (size_t)want * 4);
@@ -244,7 +344,7 @@ int read_payload(xv_ark_reader* r, float* dst) {
   // arithmetic is done in double and rounded once, like Kaldi's CompressedMatrix
   const size_t total = (size_t)cols * 8 + (size_t)n;
   if (!fill(r, total)) return fail(r, "truncated compressed-matrix payload");
-  const unsigned char* q = r->buf.data() + r->pos;
+  const unsigned char* q = r->win + r->pos;
   if (dst) {
     const double gmin = r->pending_min, grange = r->pending_range;
     const unsigned char* data = q + (size_t)cols * 8;
@@ -286,6 +386,9 @@ int xv_ark_open(const char* path, int fd, xv_ark_reader** out) {
     r->fd = fd;
   }
   r->buf.resize(kChunk);
+  r->win = r->buf.data();
+  if (path) map_file(r, true);
+  r->copy_threads = default_copy_threads();
   *out = r;
   return XV_OK;
 }
@@ -299,7 +402,9 @@ int xv_ark_open_scp(const char* scp_path, xv_ark_reader** out) {
   if (!r) { fclose(f); return XV_ERR_HIP; }
   r->scp = true;
   r->own_fd = true;
+  r->copy_threads = default_copy_threads();
   r->buf.resize(kChunk);
+  r->win = r->buf.data();
   char* line = nullptr;
   size_t cap = 0;
   ssize_t len;
@@ -363,11 +468,14 @@ int xv_ark_next_batch(xv_ark_reader* r, int64_t max_frames, int max_utts, int mi
                       int* dim) {
   if (!r || !dst || !offsets || !keys || !n_utts || !dim || max_utts < 1) return XV_ERR_INVALID;
   r->err.clear();
+  r->copies.clear();
   int n = 0, d = -1;
   int64_t frames = 0, kpos = 0;
   offsets[0] = 0;
   while (n < max_utts && frames < max_frames) {
     if (!r->have_pending) {
+      if (r->scp && r->map && r->next_entry < r->entries.size() && r->entries[r->next_entry].path != r->cur_path)
+        run_copies(r);                                // the next entry lives in another ark: this mapping goes away
       const int rc = r->scp ? parse_scp_entry(r) : parse_header(r);
       if (rc < 0) return rc;
       if (rc == 0) break;
@@ -397,6 +505,8 @@ int xv_ark_next_batch(xv_ark_reader* r, int64_t max_frames, int max_utts, int mi
     frames += rows;
     offsets[++n] = (int32_t)frames;
   }
+  run_copies(r);
+  if (r->copy_failed) { r->copy_failed = false; return fail(r, "pread failed inside a matrix payload"); }
   *n_utts = n;
   *dim = d < 0 ? 0 : d;
   return n;
@@ -411,10 +521,17 @@ int xv_ark_pending_shape(const xv_ark_reader* r, int32_t* rows, int32_t* cols) {
 
 int64_t xv_ark_skipped(const xv_ark_reader* r) { return r ? r->skipped_short : 0; }
 
+int xv_ark_set_copy_threads(xv_ark_reader* r, int n) {
+  if (!r) return XV_ERR_INVALID;
+  r->copy_threads = n < 1 ? 1 : (n > 16 ? 16 : n);
+  return XV_OK;
+}
+
 const char* xv_ark_error(const xv_ark_reader* r) { return r ? r->err.c_str() : "null reader"; }
 
 void xv_ark_close(xv_ark_reader* r) {
   if (!r) return;
+  unmap_file(r);
   if (r->own_fd && r->fd >= 0) close(r->fd);
   delete r;
 }

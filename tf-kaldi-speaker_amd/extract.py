@@ -223,21 +223,24 @@ def _vad_lookup(vad_rspecifier):
 def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normalize, batch_frames, cmn_window=0,
                vad_rspecifier=""):
     """Fast path of the driver: the native batch reader (csrc/ark_io.cpp) parses ark records straight into
-    pinned staging buffers on a background thread (outside the GIL) while this thread runs the device and
-    writes the previous batch; vectors are formatted per batch.  Batches containing an utterance longer
-    than chunk_size go through the generic chunking path on views of the same buffer."""
+    pinned staging buffers on a background thread (outside the GIL); this thread enqueues H2D + forward + D2H of batch i
+    and only then waits for, normalises and writes batch i - 1, so the device always has the next batch queued while
+    the host formats vectors.  Batches containing an utterance longer than chunk_size go through the generic chunking
+    path on views of the same buffer."""
     import queue
     import threading
     import torch
     from . import native_ark
     cap = (batch_frames + 65536) * 64
-    pins = [torch.empty(cap, dtype=torch.float32, pin_memory=True) for _ in range(3)]
+    # four staging buffers: one being filled, one queued, one in flight on the device (its H2D may not have run yet when
+    # the next batch is taken from the queue), one spare -- batch i is written out before batch i + 2 is taken
+    pins = [torch.empty(cap, dtype=torch.float32, pin_memory=True) for _ in range(4)]
     frontend = cmn_window > 0 or bool(vad_rspecifier)
     vad_of = _vad_lookup(vad_rspecifier) if vad_rspecifier else None
     # with the front-end on, the min-length rule applies to the lengths after frame selection
     reader = native_ark.ArkBatchReader(rspecifier, batch_frames=batch_frames, min_frames=1 if frontend else min_chunk_size,
                                        buffers=[p.numpy() for p in pins])
-    q = queue.Queue(maxsize=1)            # 3 buffers: one being filled, one queued, one in use
+    q = queue.Queue(maxsize=1)
     end = object()
 
     def producer():
@@ -251,6 +254,21 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
     threading.Thread(target=producer, daemon=True).start()
     done = extra_skipped = 0
     dev_index = trainer._device_index
+    pending = []                          # [(keys, pinned embeddings, event)]: batches enqueued on the device, oldest first
+    emb_pins = [None, None]               # flat pinned result buffers, used alternately
+
+    def flush(keep=0):
+        nonlocal done
+        while len(pending) > keep:
+            keys_p, host_p, ev = pending.pop(0)
+            ev.synchronize()
+            emb = trainer._checked(host_p.numpy())
+            if normalize:
+                emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
+            writer.write(keys_p, emb)
+            done += len(keys_p)
+
+    turn = 0
     while True:
         b = q.get()
         if b is end:
@@ -258,6 +276,8 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
         if isinstance(b, BaseException):
             raise b
         keys, offsets, feats = b
+        if frontend or np.diff(offsets).max() > chunk_size:
+            flush()                                     # these paths write synchronously: keep the output order
         if frontend:
             from .frontend import cmn_select_packed
             vads = [vad_of(k) for k in keys] if vad_of else None
@@ -291,11 +311,18 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
         host = torch.from_numpy(feats)                  # view of the pinned staging buffer
         with torch.cuda.device(dev_index):
             dev = host.to("cuda:%d" % dev_index, non_blocking=True)
-            emb = trainer._checked(trainer.predict_packed(dev, offsets).cpu().numpy())
-        if normalize:
-            emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
-        writer.write(keys, emb)
-        done += len(keys)
+            out = trainer.predict_packed(dev, offsets)
+            flat = emb_pins[turn & 1]
+            if flat is None or flat.numel() < out.numel():
+                flat = emb_pins[turn & 1] = torch.empty(max(out.numel(), 4096 * out.shape[1]), dtype=torch.float32, pin_memory=True)
+            host_out = flat[:out.numel()].view(out.shape)
+            host_out.copy_(out, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        turn += 1
+        pending.append((list(keys), host_out, ev))
+        flush(keep=1)                                   # write batch i - 1 while the device runs batch i
+    flush()
     skipped = reader.skipped + extra_skipped
     reader.close()
     return done, skipped

@@ -16,7 +16,7 @@ from .kaldi_io import open_or_fd
 
 
 class ArkBatchReader(object):
-    def __init__(self, rspecifier, batch_frames=76800, min_frames=0, max_utts=4096, buffers=None, capacity=None):
+    def __init__(self, rspecifier, batch_frames=76800, min_frames=0, max_utts=4096, buffers=None, capacity=None, copy_threads=None):
         """buffers: optional list of >= 2 float32 arrays (e.g. numpy views of pinned torch tensors) that are
         filled round-robin; a batch stays valid until `len(buffers) - 1` further batches have been read."""
         self._lib = _lib.load()
@@ -39,6 +39,8 @@ class ArkBatchReader(object):
             rc = self._lib.xv_ark_open(plain.encode(), -1, C.byref(self._r))
         if rc < 0:
             raise IOError("cannot open %s" % rspecifier)
+        if copy_threads is not None:
+            self._lib.xv_ark_set_copy_threads(self._r, int(copy_threads))
         self.batch_frames = int(batch_frames)
         self.min_frames = int(min_frames)
         self.max_utts = int(max_utts)
