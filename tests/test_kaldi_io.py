@@ -157,6 +157,39 @@ def test_native_reader_errors(native, tmp_path):
         native.ArkBatchReader("feats.ark.gz")
 
 
+@pytest.mark.parametrize("threads", [1, 3, 16])
+def test_native_reader_mapped_file_with_copy_threads(native, tmp_path, threads):
+    """An ark opened by name is mapped and the payloads of a batch are pread() by several threads, each taking a
+    contiguous share of the batch's bytes (a share may begin inside a record): every byte must arrive, for any thread
+    count, in ark and in scp mode (two arks, so that the mapping changes inside a batch), and a file that ends inside a
+    payload is an error, not a short copy."""
+    rs = np.random.RandomState(5)
+    lens = rs.randint(100, 900, size=60)
+    mats = [rs.standard_normal((int(t), 30)).astype(np.float32) for t in lens]      # 3.6 MB: above the threading threshold
+    paths = [str(tmp_path / "a.ark"), str(tmp_path / "b.ark")]
+    lines = []
+    for j, path in enumerate(paths):
+        with open(path, "wb") as f:
+            for i in range(j, len(mats), 2):
+                f.write(("u%03d " % i).encode())
+                lines.append((i, "u%03d %s:%d" % (i, path, f.tell())))
+                kaldi_io.write_mat(f, mats[i])
+    scp = str(tmp_path / "feats.scp")
+    with open(scp, "w") as f:
+        f.write("\n".join(line for _, line in sorted(lines)) + "\n")
+    for spec, order in (("ark:" + paths[0], list(range(0, len(mats), 2))), ("scp:" + scp, list(range(len(mats))))):
+        r = native.ArkBatchReader(spec, batch_frames=10 ** 6, copy_threads=threads)
+        got = [(k, feats[off[i]:off[i + 1]].copy()) for ks, off, feats in r for i, k in enumerate(ks)]
+        r.close()
+        assert [k for k, _ in got] == ["u%03d" % i for i in order]
+        for (k, m), i in zip(got, order):
+            np.testing.assert_array_equal(m, mats[i])
+    with open(paths[0], "r+b") as f:
+        f.truncate(os.path.getsize(paths[0]) - 1000)
+    with pytest.raises(IOError):
+        list(native.ArkBatchReader("ark:" + paths[0], batch_frames=10 ** 6, copy_threads=threads))
+
+
 def test_native_format_vectors_is_byte_identical(native):
     exp = np.load(os.path.join(GOLD, "vectors_expected.npz"))
     with open(os.path.join(GOLD, "vectors.ark"), "rb") as f:
