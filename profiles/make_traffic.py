@@ -3,7 +3,7 @@
 summaries written by summarize_pmc.py.  usage: make_traffic.py <round dir>
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md: both counters are in KB;
 FETCH_SIZE under-reports 16 B/lane streaming reads by 2x on gfx950, so it is doubled.
-A layer is the sum of its launches: main tiles + (tail K-split slices + reduce) where the tail form is active."""
+A layer is the sum of its launches: tiles (whole tiles and the K-split slices of the tail tiles share one launch) + the tail reduce."""
 import json
 import re
 import sys
@@ -12,8 +12,7 @@ import sys
 PARTS = [
     ("im2col_sb_kernel", 1228800, None, "tdnn1_conv"),                                           # feature rows -> SB rows (staging of L1)
     ("w14p2_kernel", 614400, None, "tdnn1_conv"),                                                # L1: 5 taps over 32-channel padded rows
-    ("w14p2_kernel", 589824, 0, "tdnn2_conv"), ("w14p2_kernel", 589824, 1, "tdnn3_conv"),           # main tiles, tail form
-    ("w14p2_tail_kernel", 65536, 0, "tdnn2_conv"), ("w14p2_tail_kernel", 65536, 1, "tdnn3_conv"),
+    ("w14p2_kernel", 655360, 0, "tdnn2_conv"), ("w14p2_kernel", 655360, 1, "tdnn3_conv"),           # whole tiles + K-split tail slices
     ("tail_reduce_kernel", 262144, None, "tdnn2_conv"), ("tail_reduce_kernel", 131072, None, "tdnn3_conv"),
     ("w1p3_kernel", 585728, None, "tdnn4_dense"), ("w1p3_kernel", 1757184, None, "tdnn5_dense"),
 ]

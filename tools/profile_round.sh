@@ -17,6 +17,10 @@ step att_f16; python bench.py --pooling self_attention --precision f16x3 --cpu-s
 step ab; for n in tdnn att resnet; do python tools/ab_options.py slab3 $n 2>&1 | grep -v amdgpu.ids; done > $out/ab_slab3.txt 2>&1
 python tools/ab_options.py att_fusion att 2>&1 | grep -v amdgpu.ids > $out/ab_att_fusion.txt 2>&1
 python tools/ab_options.py pool_fusion tdnn 2>&1 | grep -v amdgpu.ids > $out/ab_pool_fusion.txt 2>&1
+python tools/ab_options.py tail_split tdnn 2>&1 | grep -v amdgpu.ids > $out/ab_tail_split.txt 2>&1
+python tools/ab_options.py grid_compact resnet 2>&1 | grep -v amdgpu.ids > $out/ab_grid_compact.txt 2>&1
+python tools/reader_rate.py 100000 /tmp 2>&1 | grep -v amdgpu.ids > $out/reader_rate.txt
+for n in tdnn att resnet; do python tools/two_streams.py $n 2 2>&1 | grep -v amdgpu.ids | tail -2; done > $out/two_streams.txt 2>&1
 step cli; python tools/cli_throughput.py 100000 2>&1 | grep -v amdgpu.ids > $out/cli_throughput.txt; python tools/cli_throughput.py 300000 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt; python tools/cli_throughput.py 50000 --varlen 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt; python tools/cli_throughput.py 150000 --varlen 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt
 step trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --cpu-seconds 0 --no-extra > $out/trace.log 2>&1
 step pmc_sq; timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -- python bench.py --cpu-seconds 0 --no-extra --steps 3 --warmup 1 --no-profile > $out/pmc_sq.log 2>&1
@@ -25,6 +29,9 @@ step pmc_write; timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --ou
 step trace_att; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_att -- python bench.py --pooling self_attention --cpu-seconds 0 --no-extra > $out/trace_att.log 2>&1
 python profiles/summarize_trace.py $(find $out/trace_att -name "*kernel_trace.csv" | head -1) > $out/per_layer_summary_att.txt 2>&1
 rm -rf $out/trace_att
+step trace_resnet; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_resnet -- python bench.py --network resnet_18 --batch 64 --dim 40 --cpu-seconds 0 --no-extra > $out/trace_resnet.log 2>&1
+python profiles/summarize_trace.py $(find $out/trace_resnet -name "*kernel_trace.csv" | head -1) > $out/per_layer_summary_resnet.txt 2>&1
+rm -rf $out/trace_resnet
 step summarise
 python profiles/summarize_trace.py $(find $out/trace -name "*kernel_trace.csv" | head -1) > $out/per_layer_summary.txt 2>&1
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
