@@ -4,21 +4,25 @@
 //   x = hi + lo (+ O(2^-17 |x|)),  hi = rn_bf16(x), lo = rn_bf16(x - hi)
 //   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (dropped terms ~2^-17 |a b|)
 //
-// Three v_mfma_f32_32x32x16_bf16 per product tile, fp32 accumulate: 16/3 = 5.3x the rate of the
-// exact v_mfma_f32_32x32x2_f32 path at a relative error of ~1e-5 per layer (measured in
-// tests/test_gpu_parity.py against the float64 oracle; the bar is 1e-4).
+// Three v_mfma_f32_16x16x32_bf16 (or _f16: XV_PREC_F16X3) per product tile, fp32 accumulate: 16/3 = 5.3x the rate of
+// the exact v_mfma_f32_32x32x2_f32 path at a relative error of ~5e-6 per layer (measured in
+// tests/test_gpu_parity.py against the float64 oracle; the bar is 1e-4).  The lab kernels below still use the
+// 32x32x16 shape, on which the chip holds a lower clock (xv_epilogue.h, mfma_split16).
 //
 // Both operands arrive in the split-blocked format of xv_epilogue.h: per row, 128-byte blocks
 // [32 x bf16 hi | 32 x bf16 lo].  One block is one K step of 32 for one row, so
 //   * every global access is a full 128-byte line (8 lanes x 16 bytes),
-//   * 16-byte chunk q of a block is exactly the MFMA fragment of plane q>>2, k16-step (q>>1)&1,
-//     lane-half q&1 -- one ds_read_b128 per fragment, no repacking anywhere,
+//   * 16-byte chunk q of a block is exactly a lane's MFMA fragment: plane q>>2 (hi / lo), k chunk q&3 = lane>>4 of
+//     the 16x16x32 shape (k16-step (q>>1)&1, lane-half q&1 of 32x32x16) -- one ds_read_b128 per fragment, no repacking,
 //   * a temporal convolution stays an "overlapping-row" GEMM: row m of A is the contiguous
 //     run of w*cin/32 blocks that starts at frame m.
 //
-// The product kernel, on 128x128 workgroup tiles of 256 threads:
-//   gemm_bf16x3_w14p2_kernel  activation slabs by LDS-DMA, weight fragments straight into registers two steps
-//                             ahead, one wave per 32-channel block, counted waits (+ its K-split tail form).
+// The product kernels, on 128x128 workgroup tiles of 256 threads:
+//   gemm_bf16x3_w14p2_kernel  multi-tap convolutions: activation slabs by LDS-DMA (two buffers, one slab per channel
+//                             block), weight fragments straight into registers two steps ahead, one wave per
+//                             32-channel block, counted waits; the K-split slices of the tail tiles ride in the same launch;
+//   gemm_bf16x3_w1p3_kernel   one-tap layers (dense, attention epilogues, ResNet grid convolutions incl. the gathered
+//                             compact-row form): three slab buffers, slabs two steps ahead.
 // Lab builds only (-DXV_LAB; tools/ab_variants.sh -- never in the shipped library):
 //   gemm_bf16x3_dma_kernel    its predecessor, the A/B baseline (XVEC_GEMM_TILE=1) and the vehicle of the timing
 //                             ablations (XVEC_GEMM_DIAG, which produce wrong results on purpose): both operands by
@@ -544,7 +548,8 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
 // slabs rotate through THREE buffers (52 KB of LDS, still three workgroups per CU) and are issued TWO steps ahead, like
 // the weights; the wait at the end of step s only has to retire slab s + 1, issued a whole step earlier:
 //   VMEM order per step:  D x 4 (slab s+2, top) , a0 a1 a2 a3 (weights s+2)
-//   before group 0 / 4: vmcnt(15) as in w14p2 (same instruction counts per step); end of step: vmcnt(12)
+//   before the first MFMA: vmcnt(13) [younger than the weights of step s: slab s+1 (4), weights s+1 (4), slab s+2 (4),
+//   the first weight load of s+2 (1)]; end of step: vmcnt(12)
 //   [younger than slab s+1: weights s+1 (4), slab s+2 (4), weights s+2 (4)], then the workgroup barrier (RAW for the slab
 //   read in step s+1; WAR for buffer (s+3) % 3 = s % 3, refilled at the top of step s+1).
 // The loop is unrolled by three, so the slab buffer of a step is a compile-time constant like its weight registers.

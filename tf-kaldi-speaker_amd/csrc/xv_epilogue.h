@@ -1,11 +1,12 @@
-// Shared GEMM epilogue for the 32x32 MFMA accumulator layout (gfx950), and the "split-blocked"
-// (SB) activation format of the bf16x3 path.
+// Shared GEMM epilogues (gfx950): the 16x16 accumulator layout of the split-precision product kernels
+// (store_wave_tile_n32*), the 32x32 layout of the fp32 kernel and the lab kernels (store_wave_tile), and the
+// "split-blocked" (SB) activation format of the bf16x3 / f16x3 path.
 //
 // SB format: a row of C channels is stored as ceil(C/32) blocks of 128 bytes; block j holds
 // channels 32j..32j+31 as [32 x bf16 hi | 32 x bf16 lo] with hi = rn_bf16(x), lo = rn_bf16(x - hi)
 // (hi + lo carries 16 significant bits).  Same bytes per element as fp32; one (row, block) is
-// one full 128-byte line, and 16-byte chunk q of a block is plane q>>2, k-step (q>>1)&1,
-// lane-half q&1 of the v_mfma_f32_32x32x16_bf16 A/B fragments.
+// one full 128-byte line, and 16-byte chunk q of a block is plane q>>2 (hi / lo), k chunk q&3 (= lane>>4) of the
+// v_mfma_f32_16x16x32_bf16 A/B fragments.
 #pragma once
 #include "xv_kernels.h"
 

@@ -119,7 +119,7 @@ int64_t gemm_bf16x3_tail_plan(int M, int Kpad, int Npad, int w, int* tail_mt, in
 hipError_t launch_im2col_sb(const float* x, int64_t ldx, int cin, int w, int64_t rows, void* out_sb, int ldsb, int f16,
                             int* ovf, hipStream_t s);
 
-// bf16x3 split path (3x v_mfma_f32_32x32x16_bf16 per product tile).
+// bf16x3 / f16x3 split path (3x v_mfma_f32_16x16x32_{bf16,f16} per product tile).
 hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s);
 
 // rowmap for a valid convolution of width w over packed utterances:
