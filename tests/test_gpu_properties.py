@@ -101,6 +101,32 @@ def test_long_utterance_chunking_equals_weighted_mean():
     tr.close()
 
 
+def test_extreme_geometries_many_tiny_and_one_huge_utterance():
+    """The two ends of what a launcher batch can look like (extract.py:65-86: minimum length 25 by default, chunks of up to
+    10 000 frames): 3 000 utterances of 15-40 frames (15 = the network's context + 1: one output frame; row maps and pooling
+    segments dominate, every 64-row pooling pass spans several utterances) and one utterance of 12 000 frames next to a
+    15-frame one (a pooling segment of 187 passes).  Split path against the exact path everywhere, the oracle on a sample."""
+    from oracle import ref_numpy
+    from tf_kaldi_speaker_amd import synth
+    rs = np.random.RandomState(9)
+    tiny = [int(t) for t in rs.randint(15, 41, size=3000)]
+    tr16, weights, params = _make("bf16x3")
+    tr32, _, _ = _make("f32")
+    for lens, sample in ((tiny, (0, 1499, 2999)), ([12000, 15], (1,))):
+        utts = synth.synth_features(len(lens), lens, 30, seed=78)
+        e16, e32 = _run(tr16, utts), _run(tr32, utts)
+        assert np.isfinite(e16).all() and e16.shape == (len(lens), 512)
+        rel = np.linalg.norm(e16 - e32, axis=1) / np.linalg.norm(e32, axis=1)
+        assert rel.max() <= 2e-5, rel.max()
+        for i in sample:
+            ref = ref_numpy.predict(utts[i], weights, params, 30)
+            assert np.linalg.norm(e16[i] - ref) / np.linalg.norm(ref) <= 1e-4
+        again = _run(tr16, utts)
+        assert np.array_equal(again, e16)
+    tr16.close()
+    tr32.close()
+
+
 def test_attention_and_resnet_batch_invariance():
     from tf_kaldi_speaker_amd import synth
     tr, _, _ = _make("bf16x3", synth.TDNN_ATT_PARAMS)
