@@ -499,12 +499,32 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
       if (g + 2 < 8) read_frag(g + 2);
       if (g == 0) XV_WAIT4(5 + 2 * NPS, Wc[0], Wc[1], Wc[2], Wc[3]);
       // small cross terms first, the dominant hi*hi term last; the two channel tiles alternate
+#ifdef XV_F6_TIMING
+      // TIMING ONLY (wrong results): the instruction mix of the proposed two-unit split on this kernel's
+      // memory traffic -- per K step the hi*hi MFMA of each tile, and every fourth step the two block-scaled fp6 cross terms of
+      // four steps, with whatever bits the operand registers hold
+      acc[g][0] = mfma_split16<true>(Wc[0], fh[g], acc[g][0]);
+      acc[g][1] = mfma_split16<true>(Wc[1], fh[g], acc[g][1]);
+      if ((s & 3) == 3) {
+        typedef int v8i_t __attribute__((ext_vector_type(8)));
+        typedef int v4i_t __attribute__((ext_vector_type(4)));
+        const v4i_t w0 = __builtin_bit_cast(v4i_t, Wc[0]), w1 = __builtin_bit_cast(v4i_t, Wc[1]), w2 = __builtin_bit_cast(v4i_t, Wc[2]),
+                    w3 = __builtin_bit_cast(v4i_t, Wc[3]), b0 = __builtin_bit_cast(v4i_t, fh[g]), b1 = __builtin_bit_cast(v4i_t, fl[g]);
+        const v8i_t a0 = {w0[0], w0[1], w0[2], w0[3], w2[0], w2[1], w2[2], w2[3]}, a1 = {w1[0], w1[1], w1[2], w1[3], w3[0], w3[1], w3[2], w3[3]};
+        const v8i_t bb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        acc[g][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a0, bb, acc[g][0], 2, 2, 0, 127, 0, 127);
+        acc[g][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a1, bb, acc[g][1], 2, 2, 0, 127, 0, 127);
+        acc[g][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a1, bb, acc[g][0], 2, 2, 0, 127, 0, 127);
+        acc[g][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a0, bb, acc[g][1], 2, 2, 0, 127, 0, 127);
+      }
+#else
       acc[g][0] = mfma_split16<F16>(Wc[0], fl[g], acc[g][0]);
       acc[g][1] = mfma_split16<F16>(Wc[1], fl[g], acc[g][1]);
       acc[g][0] = mfma_split16<F16>(Wc[2], fh[g], acc[g][0]);
       acc[g][1] = mfma_split16<F16>(Wc[3], fh[g], acc[g][1]);
       acc[g][0] = mfma_split16<F16>(Wc[0], fh[g], acc[g][0]);
       acc[g][1] = mfma_split16<F16>(Wc[1], fh[g], acc[g][1]);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     if (cb1 != cb) {                     // slab switch
@@ -689,12 +709,32 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
       if (g == 6) XV_GLD(Wn[3], q, 3072);     // lo, channels 16..31
       if (g + 2 < 8) read_frag(g + 2);
       if (g == 0) XV_WAIT4(13, Wc[0], Wc[1], Wc[2], Wc[3]);
+#ifdef XV_F6_TIMING
+      // TIMING ONLY (wrong results): the instruction mix of the proposed two-unit split on this kernel's
+      // memory traffic -- per K step the hi*hi MFMA of each tile, and every fourth step the two block-scaled fp6 cross terms of
+      // four steps, with whatever bits the operand registers hold
+      acc[g][0] = mfma_split16<true>(Wc[0], fh[g], acc[g][0]);
+      acc[g][1] = mfma_split16<true>(Wc[1], fh[g], acc[g][1]);
+      if ((s & 3) == 3) {
+        typedef int v8i_t __attribute__((ext_vector_type(8)));
+        typedef int v4i_t __attribute__((ext_vector_type(4)));
+        const v4i_t w0 = __builtin_bit_cast(v4i_t, Wc[0]), w1 = __builtin_bit_cast(v4i_t, Wc[1]), w2 = __builtin_bit_cast(v4i_t, Wc[2]),
+                    w3 = __builtin_bit_cast(v4i_t, Wc[3]), b0 = __builtin_bit_cast(v4i_t, fh[g]), b1 = __builtin_bit_cast(v4i_t, fl[g]);
+        const v8i_t a0 = {w0[0], w0[1], w0[2], w0[3], w2[0], w2[1], w2[2], w2[3]}, a1 = {w1[0], w1[1], w1[2], w1[3], w3[0], w3[1], w3[2], w3[3]};
+        const v8i_t bb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        acc[g][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a0, bb, acc[g][0], 2, 2, 0, 127, 0, 127);
+        acc[g][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a1, bb, acc[g][1], 2, 2, 0, 127, 0, 127);
+        acc[g][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a1, bb, acc[g][0], 2, 2, 0, 127, 0, 127);
+        acc[g][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a0, bb, acc[g][1], 2, 2, 0, 127, 0, 127);
+      }
+#else
       acc[g][0] = mfma_split16<F16>(Wc[0], fl[g], acc[g][0]);
       acc[g][1] = mfma_split16<F16>(Wc[1], fl[g], acc[g][1]);
       acc[g][0] = mfma_split16<F16>(Wc[2], fh[g], acc[g][0]);
       acc[g][1] = mfma_split16<F16>(Wc[3], fh[g], acc[g][1]);
       acc[g][0] = mfma_split16<F16>(Wc[0], fh[g], acc[g][0]);
       acc[g][1] = mfma_split16<F16>(Wc[1], fh[g], acc[g][1]);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // slab s + 1 has landed (this wave's pieces)
