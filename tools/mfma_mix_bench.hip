@@ -51,11 +51,13 @@ __global__ __launch_bounds__(256, 3) void mix_a(const bf16x8* __restrict__ src, 
 }
 
 // FMT: 2 = fp6 e2m3 (6 VGPRs per operand), 0 = fp8 e4m3 (8 VGPRs)
-template <int LDSREAD, int FMT>
-__global__ __launch_bounds__(256, 3) void mix_b(const f16x8* __restrict__ src, const v8i* __restrict__ src8, float* __restrict__ out,
+template <int LDSREAD, int FMT, int OCC = 3>
+__global__ __launch_bounds__(256, OCC) void mix_b(const f16x8* __restrict__ src, const v8i* __restrict__ src8, float* __restrict__ out,
                                                 int iters) {
   __shared__ f16x8 lds[4 * 2 * 64];      // two frame tiles' worth, re-read alternately (keeps three workgroups per CU)
   __shared__ v8i lds8[2 * 2 * 64];
+  __shared__ int occ_pad[OCC == 2 ? 14000 : 1];   // OCC == 2: 56 KB more, so that only two workgroups fit a CU
+  if (iters < 0) occ_pad[threadIdx.x] = iters;
   const int lane = threadIdx.x & 63;
   f16x8 W[2][4];
   v8i W8h[2], W8l[2];
@@ -143,6 +145,11 @@ int main(int argc, char** argv) {
     const double flop = 768.0 * 4 * 16 * (16.0 * 16 * 128 * 2) * 1000;
     printf("%s: 3 x bf16 %.3f ms = %.0f TF algorithmic | f16 + 2 x fp6 %.3f ms = %.0f TF (x%.2f) | f16 + 2 x fp8 %.3f ms = %.0f TF (x%.2f)\n",
            v ? "fragments from LDS " : "operands in registers", a, flop / a / 1e9, b6, flop / b6 / 1e9, a / b6, b8, flop / b8 / 1e9, a / b8);
+  }
+  {   // the proposed mix at TWO workgroups per CU (a simpler kernel could double-buffer its weights in 256 VGPRs)
+    double b6 = time_it([&] { hipLaunchKernelGGL((mix_b<1, 2, 2>), dim3(wgs), dim3(256), 0, 0, (const f16x8*)df, (const v8i*)d8, out, itB); }, seconds);
+    const double flop = 768.0 * 4 * 16 * (16.0 * 16 * 128 * 2) * 1000;
+    printf("fragments from LDS, two workgroups per CU: f16 + 2 x fp6 %.3f ms = %.0f TF\n", b6, flop / b6 / 1e9);
   }
   CHECK(hipDeviceSynchronize());
   return 0;
