@@ -199,6 +199,73 @@ __global__ void im2col2d_kernel(const float* __restrict__ x, int64_t ldx, const 
   }
 }
 
+// conv0 directly (split precisions): one workgroup per padded time row of the batch, one thread per (position of the row, 8
+// channels).  The workgroup finds its utterance once, stages the three feature rows of the window (zero padded: TF 'same',
+// stride 1, one row / column each side) and the 9 x C kernel + BN scale / shift in LDS; an interior position sums its 3x3 window
+// in fp32, applies scale / shift and the activation and stores 8 fp32 values and / or the 16-byte hi and lo chunks of its
+// split-blocked row; border positions are written as zeros.  K = 9: the matrix pipe has nothing to do here -- as im2col + GEMM
+// the layer was one K step of prologue and epilogue around a 100 MB detour.
+constexpr int kConv0MaxC = 256, kConv0MaxF = 126;
+__global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ off0,
+                                                          int B, int F, int S, int C, const float* __restrict__ wdir, int act,
+                                                          const float* __restrict__ alpha, float* __restrict__ y,
+                                                          char* __restrict__ ysb, int ldsb, int f16, int* __restrict__ ovf) {
+  __shared__ float xs[3][kConv0MaxF + 2];
+  __shared__ float wsm[11 * kConv0MaxC];
+  const int64_t r = blockIdx.x;                               // padded time row of the batch
+  const int b = find_utt(off0, B, 1, r);
+  const int tp = (int)(r - (off0[b] + 2 * b));
+  const int L = off0[b + 1] - off0[b];
+  const bool inside = tp >= 1 && tp <= L;
+  if (inside) {
+    for (int i = threadIdx.x; i < 11 * C; i += 256) wsm[i] = wdir[i];
+    for (int i = threadIdx.x; i < 3 * (F + 2); i += 256) {
+      const int kh = i / (F + 2), c = i - kh * (F + 2);
+      const int tt = tp - 2 + kh, ff = c - 1;                 // feature row / bin of window row kh, column c
+      xs[kh][c] = (tt >= 0 && tt < L && ff >= 0 && ff < F) ? x[(int64_t)(off0[b] + tt) * ldx + ff] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int groups = C >> 3;
+  for (int item = threadIdx.x; item < S * groups; item += 256) {
+    const int fp = item / groups, c0 = (item - fp * groups) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (inside && fp >= 1 && fp <= F) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float xv = xs[kh][fp - 1 + kw];
+          const float* w = wsm + (kh * 3 + kw) * C + c0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(xv, w[e], v[e]);
+        }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] = apply_act(fmaf(v[e], wsm[9 * C + c0 + e], wsm[10 * C + c0 + e]), act, alpha ? alpha[c0 + e] : 0.f);
+    }
+    const int64_t p = r * S + fp;
+    if (y) {
+      float* o = y + p * C + c0;
+      *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+    if (ysb) {
+      uint32_t hi[4], lo[4];
+      float m = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        split2(v[2 * e], v[2 * e + 1], hi[e], lo[e], f16);
+        m = fmaxf(m, fmaxf(fabsf(v[2 * e]), fabsf(v[2 * e + 1])));
+      }
+      if (f16) ovf_report(ovf, m);
+      char* blk = ysb + p * (int64_t)ldsb * 4 + (c0 >> 5) * 128 + (c0 & 31) * 2;
+      *reinterpret_cast<uint4*>(blk) = uint4{hi[0], hi[1], hi[2], hi[3]};
+      *reinterpret_cast<uint4*>(blk + 64) = uint4{lo[0], lo[1], lo[2], lo[3]};
+    }
+  }
+}
+
 // 3x3 stride-1 'same' max-pool on a grid value (model/resnet.py:230-231): one thread per (position, 4 channels).  An
 // interior position takes the maximum over its neighbours INSIDE the map (TensorFlow's 'same' max-pool ignores the
 // padding, so the zero border must not take part: leaky / parametric ReLU outputs can be negative); a border
@@ -296,6 +363,17 @@ hipError_t launch_grid_zero_border(const int32_t* off0, int B, int64_t frames, i
   const int64_t blocks = (nborder * cmax + 255) / 256;
   hipLaunchKernelGGL(grid_zero_border_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, off0, B, F, S,
                      y ? chunks_y : 0, ysb ? chunks_sb : 0, reinterpret_cast<char*>(y), static_cast<char*>(ysb), nborder);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv0_direct(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int S, int C, int64_t P,
+                               const float* wdir, int act, const float* alpha, float* y, void* ysb, int ldsb, int f16, int* ovf,
+                               hipStream_t s) {
+  const int64_t rows = S > 0 ? P / S : 0;                     // padded time rows of the batch
+  if (rows <= 0) return hipSuccess;
+  if (C > kConv0MaxC || F > kConv0MaxF || (C & 7) || rows * S != P) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(conv0_direct_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, ldx, off0, B, F, S, C, wdir, act, alpha, y,
+                     static_cast<char*>(ysb), ldsb, f16, ovf);
   return hipGetLastError();
 }
 

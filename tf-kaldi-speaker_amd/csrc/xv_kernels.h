@@ -168,6 +168,11 @@ hipError_t launch_im2col2d_sb(const float* x, int64_t ldx, const int32_t* off0, 
 hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int S, int64_t P, float* out,
                                hipStream_t s);
 // 3x3 stride-1 'same' max-pool of a grid value [P, C] (fp32 in; fp32 and / or SB out, either may be null); borders -> 0
+// conv0 of the ResNet (3x3 'same' on the 1-channel feature map, model/resnet.py:217-228) computed directly: fp32 FMAs, BN scale /
+// shift + activation, fp32 and / or split-blocked grid output (pitch S, border positions zero).  wdir = [9][C] kernel, scale[C], shift[C].
+hipError_t launch_conv0_direct(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int S, int C, int64_t P,
+                               const float* wdir, int act, const float* alpha, float* y, void* ysb, int ldsb, int f16, int* ovf,
+                               hipStream_t s);
 hipError_t launch_grid_maxpool3x3(const float* x, const int32_t* off0, int B, int F, int S, int C, int64_t P, float* y,
                                   void* ysb, int ldsb, int f16, int* ovf, hipStream_t s);
 // grid [P, C] -> dense [sum L_b * F, C] (drops the zero border; test / endpoint output only)

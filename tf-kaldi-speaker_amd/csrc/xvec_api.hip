@@ -87,6 +87,7 @@ struct Layer {
   bool has_bias = true;
   int K() const { return mode == 1 ? 9 * cin : (mode == 3 ? Fin * cin : (mode == 4 ? 9 : w * cin)); }
   DevBuf vec;                 // [bias | bn_scale | bn_shift | alpha | ones] each cout floats
+  DevBuf wdir;                // conv0 (mode 4): fp32 [9][cout] kernel, then bn_scale[cout], bn_shift[cout] (direct kernel, csrc/grid.hip)
   int Kpad = 0, Npad = 0;
   int final_stage() const { return act != ACT_NONE ? ST_ACT : (has_bn ? ST_BN : ST_AFFINE); }
   const float* d_bias() const { return static_cast<const float*>(vec.p); }
@@ -668,6 +669,14 @@ int upload_layer(xv_handle* h, Layer& L) {
   XV_HIP(h, L.vec.alloc(vec.size() * sizeof(float)));
   XV_HIP(h, hipMemcpy(L.vec.p, vec.data(), vec.size() * sizeof(float), hipMemcpyHostToDevice));
 
+  if (L.mode == 4) {                                  // conv0_direct_kernel: the 9 x cout kernel as it is, true BN scale / shift
+    std::vector<float> wd((size_t)11 * N);
+    for (int k = 0; k < 9; ++k)
+      for (int n = 0; n < N; ++n) wd[(size_t)k * N + n] = W[(size_t)k * N + n];
+    for (int n = 0; n < N; ++n) { wd[(size_t)9 * N + n] = vec[(size_t)N + n]; wd[(size_t)10 * N + n] = vec[(size_t)2 * N + n]; }
+    XV_HIP(h, L.wdir.alloc(wd.size() * sizeof(float)));
+    XV_HIP(h, hipMemcpy(L.wdir.p, wd.data(), wd.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   const size_t elems = (size_t)L.Npad * L.Kpad;
   if (!L.use_split) {
     std::vector<float> wt(elems, 0.f);
@@ -1513,6 +1522,17 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         if (L.mode == 4) {                  // conv0: 3x3 on the 1-channel input = im2col (9 taps, padded to 32) + dense GEMM
           if (st.scratch_off < 0) return fail(h, XV_ERR_STATE, "conv0 has no scratch");
           a.cin = 32; a.K = 32;             // taps 9..31 are zero in both operands
+          // split precisions, final stage, not the requested node: nine fp32 FMAs per output on the vector units, BN +
+          // activation + split store fused (one pass over the 200 MB output instead of im2col rows + a one-step GEMM)
+          const bool direct = L.use_split && !st.to_out && st.stage == L.final_stage() && L.cout % 8 == 0 &&
+                              (st.out_sb_off < 0 || L.cout % 32 == 0) && L.cout <= 256 && L.wdir.p;
+          if (direct) {
+            XV_HIP(h, launch_conv0_direct(feats, feat_ld, off, B, L.Fout, vo.grid_S, L.cout, st.M, static_cast<const float*>(L.wdir.p),
+                                          L.act, L.d_alpha(), st.out_off >= 0 ? reinterpret_cast<float*>(ws + st.out_off) : nullptr,
+                                          st.out_sb_off >= 0 ? ws + st.out_sb_off : nullptr, sb_ld(L.cout), f16,
+                                          static_cast<int*>(h->ovf_flag.p), s));
+            break;
+          }
           if (L.use_split) {
             XV_HIP(h, launch_im2col2d_sb(feats, feat_ld, off, B, L.Fout, vo.grid_S, st.M, ws + st.scratch_off, f16, static_cast<int*>(h->ovf_flag.p), s));
             a.Xsb = ws + st.scratch_off; a.ldsbx = 32; a.Wsb = L.wsb.p; a.Wfr = L.wfr.p;
