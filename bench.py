@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 FLOP_PER_UTT_300 = 2452865024          # BASELINE.md section 2 (L1..L6, T=300)
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0}   # MI355X_MICROARCH.md: fp32 MFMA / bf16 = f16 MFMA dense
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0, "f16f6": 2500.0}   # MI355X_MICROARCH.md: fp32 MFMA / bf16 = f16 MFMA dense
 HBM_PEAK_GBS = 8000.0
 
 
@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--dim", type=int, default=30)
-    ap.add_argument("--precision", default=os.environ.get("XVEC_PRECISION", ""), help="f32 | bf16x3 | f16x3 (default: library default)")
+    ap.add_argument("--precision", default=os.environ.get("XVEC_PRECISION", ""), help="f32 | bf16x3 | f16x3 | f16f6 (default: library default)")
     ap.add_argument("--pooling", default="statistics_pooling", choices=["statistics_pooling", "self_attention"])
     ap.add_argument("--network", default="tdnn", choices=["tdnn", "extended_tdnn", "resnet_18"],
                     help="tdnn = BASELINE configs 1-4; resnet_18 = config 5 (use --dim 40 --batch 64)")
@@ -419,7 +419,7 @@ def main():
             "value": round(value, 1), "unit": "utterances/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "prewarm_s": args.prewarm, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x3": "bf16x3(f32-split)", "f16x3": "f16x3(f32-split)"}[precision], "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x3": "bf16x3(f32-split)", "f16x3": "f16x3(f32-split)", "f16f6": "f16+fp6-cross(f32-split)"}[precision], "data": "synthetic",
             "config": {"workload": "%s x-vector (%s), %s, %d utt/GPU/step of %s frames x %d dims"
                        % (args.network, params.embedding_node, args.pooling, args.batch,
                           "U[200,1000]" if args.varlen else str(args.frames), args.dim),

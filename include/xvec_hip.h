@@ -65,11 +65,15 @@ enum {
   XV_PREC_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate   */
   XV_PREC_BF16X3 = 1,  /* 3x v_mfma_f32_16x16x32_bf16 on hi/lo bf16 splits, fp32 accumulate
                           (~5e-6 relative per layer; meets the 1e-4 parity bar at 5x the MFMA rate; full fp32 range) */
-  XV_PREC_F16X3 = 2    /* 3x v_mfma_f32_16x16x32_f16 on hi/lo fp16 splits, fp32 accumulate: same kernels, layout and
+  XV_PREC_F16X3 = 2,   /* 3x v_mfma_f32_16x16x32_f16 on hi/lo fp16 splits, fp32 accumulate: same kernels, layout and
                           rate as bf16x3 with 22 instead of 16 significand bits per operand (~3e-7 relative).  Weights
                           are pre-scaled per layer by a power of two into the fp16 range (undone in the epilogue);
                           activations / input features beyond +-65504 overflow to inf -- outputs are then non-finite and
                           the host mirror raises instead of returning them */
+  XV_PREC_F16F6 = 3    /* f16x3 everywhere except the multi-tap temporal convolutions (4..8 taps, whole 32-channel blocks),
+                          which compute hi*hi on v_mfma_f32_16x16x32_f16 and the two cross terms on the block-scaled fp6
+                          path (v_mfma_scale_f32_16x16x128_f8f6f4, e2m3, one scale per 32 channels): 1.5 MFMA units per
+                          product instead of 3, ~1e-5 relative on the x-vector (bar 1e-4).  Same range rule as f16x3. */
 };
 
 #define XV_MAX_ATT_LAYERS 4

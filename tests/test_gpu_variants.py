@@ -232,6 +232,44 @@ def test_compact_grid_rows_are_bit_identical_to_the_full_enumeration(kw):
             assert np.array_equal(a[node], a2[node]), (kw, prec, node, "second forward")
 
 
+@pytest.mark.parametrize("net", ["tdnn", "tdnn_narrow", "etdnn"])
+def test_f16f6_two_unit_split(net):
+    """XV_PREC_F16F6: the 5- and 7-tap convolutions compute hi*hi in fp16 and the two cross terms on the block-scaled fp6 path
+    (csrc/gemm_f16f6.hip: 1.5 MFMA units per product instead of 3).  tools/f16f8_error_model.py predicts ~1e-5 on the x-vector;
+    the bar is the path's 1e-4 against the float64 oracle, on every stage endpoint of the converted layers (their conv / bn
+    stages run through the same kernel with other epilogue vectors) and on the embedding; against the exact fp32 path the
+    frame-level layers must stay within 5e-5.  Ragged batch with the shortest possible utterance; narrow variant: 64 channels
+    (two channel blocks, N below the tile); extended TDNN: its 9-tap layer is not eligible and stays on f16x3.  Deterministic."""
+    from oracle import ref_numpy
+    from tf_kaldi_speaker_amd import synth
+    import torch
+    ch = 64 if net == "tdnn_narrow" else 512
+    params = dict(synth.TDNN_STAT_PARAMS)
+    if net == "etdnn":                                  # conv1d k = 5, 5, 7, 9 at tdnn1 / 3 / 5 / 7 (model/tdnn.py:343-591)
+        params.update(network_type="extended_tdnn", embedding_node="tdnn12_dense")
+    weights = synth.synth_weights(params, 30, seed=4, channels=ch)
+    lens = [300, 64, 200, 23 if net == "etdnn" else 15, 129, 333]
+    utts = synth.synth_features(len(lens), lens, 30, seed=41)
+    feats = torch.from_numpy(np.concatenate(utts)).cuda()
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    emb = params["embedding_node"]
+    nodes = ("tdnn3_conv", "tdnn3_bn", "tdnn3_relu", "tdnn5_relu", emb) if net == "etdnn" else \
+            ("tdnn2_conv", "tdnn2_bn", "tdnn2_relu", "tdnn3_relu", emb)
+    tr = _trainer(params, weights, 30, "f16f6")
+    got = _run_nodes(tr, feats, offs, nodes)            # _run_nodes also checks bit-identical repetition
+    tr.close()
+    tr = _trainer(params, weights, 30, "f32")
+    exact = _run_nodes(tr, feats, offs, nodes)
+    tr.close()
+    for node in nodes[:-1]:
+        assert _rel2(got[node], exact[node]) <= 5e-5, (net, node, _rel2(got[node], exact[node]))
+        assert _rel2(got[node], exact[node]) >= 1e-6, (net, node, "the two-unit kernel did not run")
+    for i in (0, 3, 5):
+        ref = ref_numpy.predict(utts[i], weights, params, 30)
+        assert _rel(got[emb][i], ref) <= TOL, (net, i)
+        assert _rel(got[emb][i], ref) <= 2e-5, (net, i)                # the error model's figure, with slack
+
+
 def test_f16x3_is_tighter_than_bf16x3_and_reports_overflow():
     """The fp16 hi/lo split format (XV_PREC_F16X3): same kernels and layout as bf16x3, 22 instead of 16 significand bits.
     At the BASELINE geometry its embeddings and its (peaky) attention weights must be several times closer to the exact

@@ -18,6 +18,7 @@ XV_ERR_TOO_SHORT = -7
 XV_PREC_F32 = 0
 XV_PREC_BF16X3 = 1
 XV_PREC_F16X3 = 2
+XV_PREC_F16F6 = 3
 XV_POOL_STATISTICS = 0
 XV_POOL_SELF_ATTENTION = 1
 XV_ACT_RELU, XV_ACT_LRELU, XV_ACT_PRELU = 0, 1, 2

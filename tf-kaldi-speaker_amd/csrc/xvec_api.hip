@@ -87,6 +87,8 @@ struct Layer {
   bool has_bias = true;
   int K() const { return mode == 1 ? 9 * cin : (mode == 3 ? Fin * cin : (mode == 4 ? 9 : w * cin)); }
   DevBuf vec;                 // [bias | bn_scale | bn_shift | alpha | ones] each cout floats
+  bool use_f6 = false;        // XV_PREC_F16F6: this multi-tap convolution runs on gemm_f16f6_kernel (input converted to its block format)
+  DevBuf wf6m, wf6x;          // its weights: f16 main fragments [N/32][cin/32][8 taps][2][64 lanes][16 B]; fp6 cross operands (gemm_f16f6.hip)
   DevBuf wdir;                // conv0 (mode 4): fp32 [9][cout] kernel, then bn_scale[cout], bn_shift[cout] (direct kernel, csrc/grid.hip)
   int Kpad = 0, Npad = 0;
   int final_stage() const { return act != ACT_NONE ? ST_ACT : (has_bn ? ST_BN : ST_AFFINE); }
@@ -640,6 +642,42 @@ void bn_fold(const xv_handle* h, const std::string& scope, int n, std::vector<do
   }
 }
 
+// ---- block-scaled fp6 (e2m3) quantisation of 32 values: the host twin of e2m3_code / e8m0_of in csrc/gemm_f16f6.hip
+uint32_t host_e2m3(float x, float inv) {
+  float v = std::fmin(std::fabs(x) * inv, 7.5f);
+  const bool sub = v < 1.f;
+  const float t = sub ? v + 1.f : v;
+  uint32_t bits;
+  memcpy(&bits, &t, 4);
+  uint32_t c = ((bits + 0x80000u) >> 20) - (126u << 3) - (sub ? 8u : 0u);
+  c = c > 31u ? 31u : c;
+  return c | (x < 0.f ? 32u : 0u);
+}
+void host_quant32(const float* v, unsigned char* codes24, unsigned char* scale_byte) {
+  float amax = 0.f;
+  for (int i = 0; i < 32; ++i) amax = std::fmax(amax, std::fabs(v[i]));
+  float inv = 1.f;
+  uint32_t byte = 0;
+  if (amax > 0.f && std::isfinite(amax)) {
+    const float r = amax * (1.f / 7.5f);
+    uint32_t bits;
+    memcpy(&bits, &r, 4);
+    int e = (int)((bits + 0x7FFFFFu) >> 23) - 127;
+    e = e < -126 ? -126 : (e > 126 ? 126 : e);
+    byte = (uint32_t)(127 + e);
+    const uint32_t ib = (uint32_t)(127 - e) << 23;
+    memcpy(&inv, &ib, 4);
+  }
+  memset(codes24, 0, 24);
+  for (int i = 0; i < 32; ++i) {
+    const uint32_t c = host_e2m3(v[i], inv);
+    const int bit = 6 * i;
+    for (int q = 0; q < 6; ++q)
+      if ((c >> q) & 1) codes24[(bit + q) >> 3] |= (unsigned char)(1u << ((bit + q) & 7));
+  }
+  *scale_byte = (unsigned char)byte;
+}
+
 int upload_layer(xv_handle* h, Layer& L) {
   const int K = L.K(), N = L.cout;
   // row of the packed weight matrix that holds kernel row k: identity, or tap * cin_pad + channel for a first layer
@@ -686,7 +724,7 @@ int upload_layer(xv_handle* h, Layer& L) {
     XV_HIP(h, hipMemcpy(L.wt.p, wt.data(), elems * sizeof(float), hipMemcpyHostToDevice));
   } else {
     // split-blocked: row n, block kb: [32 x hi | 32 x lo] for k = 32*kb .. 32*kb+31 (xv_epilogue.h)
-    const bool f16 = h->desc.precision == XV_PREC_F16X3;
+    const bool f16 = h->desc.precision == XV_PREC_F16X3 || h->desc.precision == XV_PREC_F16F6;
     float wscale = 1.f;
     if (f16) {
       // fp16 hi/lo keeps 22 significand bits only while the low half stays normal (|w * s| >= 2^-3): scale the layer's
@@ -738,6 +776,42 @@ int upload_layer(xv_handle* h, Layer& L) {
         }
     XV_HIP(h, L.wfr.alloc(elems * 4));
     XV_HIP(h, hipMemcpy(L.wfr.p, fr.data(), elems * 4, hipMemcpyHostToDevice));
+    if (L.use_f6) {
+      // gemm_f16f6_kernel operands (the scaled weights w * wscale, like the f16 halves above): taps padded to 8 with zeros.
+      //   main  [Npad/32][cin/32][8 taps][2 channel tiles][64 lanes = 16 * k-chunk + channel][8 x f16]
+      //   cross [Npad/32][cin/32][2 macro steps][2 channel tiles] x { 64 x 16 B q6(hi) | 64 x 16 B q6(lo) | 64 x (8 B hi tail | 8 B lo
+      //         tail) | 64 x 4 B scales (byte 0 hi, byte 1 lo) },  lane = 16 * (tap & 3) + channel: K group = tap inside the macro step
+      const int ncb = L.cin / 32;
+      const size_t main_ct = 64 * 16, cross_ct = 64 * 16 * 3 + 64 * 4;
+      std::vector<unsigned char> wm((size_t)(L.Npad / 32) * ncb * 8 * 2 * main_ct, 0), wx((size_t)(L.Npad / 32) * ncb * 2 * 2 * cross_ct, 0);
+      for (int n = 0; n < L.Npad; ++n) {
+        const int nb = n >> 5, ct = (n >> 4) & 1, r16 = n & 15;
+        for (int cb = 0; cb < ncb; ++cb)
+          for (int j = 0; j < 8; ++j) {
+            float whi[32], wlo[32];
+            uint16_t hh[32];
+            for (int t = 0; t < 32; ++t) {
+              const float wv = (j < L.w && n < N) ? W[((size_t)j * L.cin + cb * 32 + t) * N + n] * wscale : 0.f;
+              hh[t] = f32_to_f16_rn(wv);
+              whi[t] = f16_to_f32(hh[t]);
+              wlo[t] = wv - whi[t];
+            }
+            unsigned char* pm = &wm[((((size_t)nb * ncb + cb) * 8 + j) * 2 + ct) * main_ct];
+            for (int kc = 0; kc < 4; ++kc) memcpy(pm + (16 * kc + r16) * 16, &hh[8 * kc], 16);
+            unsigned char* px = &wx[((((size_t)nb * ncb + cb) * 2 + (j >> 2)) * 2 + ct) * cross_ct];
+            const int ln = 16 * (j & 3) + r16;
+            unsigned char c24[24], sc;
+            host_quant32(whi, c24, &sc);
+            memcpy(px + ln * 16, c24, 16); memcpy(px + 2048 + ln * 16, c24 + 16, 8); px[3072 + ln * 4] = sc;
+            host_quant32(wlo, c24, &sc);
+            memcpy(px + 1024 + ln * 16, c24, 16); memcpy(px + 2048 + ln * 16 + 8, c24 + 16, 8); px[3072 + ln * 4 + 1] = sc;
+          }
+      }
+      XV_HIP(h, L.wf6m.alloc(wm.size()));
+      XV_HIP(h, hipMemcpy(L.wf6m.p, wm.data(), wm.size(), hipMemcpyHostToDevice));
+      XV_HIP(h, L.wf6x.alloc(wx.size()));
+      XV_HIP(h, hipMemcpy(L.wf6x.p, wx.data(), wx.size(), hipMemcpyHostToDevice));
+    }
   }
   return XV_OK;
 }
@@ -784,7 +858,8 @@ int xv_create(const xv_model_desc* desc, int device, xv_handle** out) {
         return fail(nullptr, XV_ERR_INVALID, "xv_create: resnet_blocks[%d] = %d", i, desc->resnet_blocks[i]);
   if (desc->feat_dim < 1 || desc->channels < 1 || desc->num_nodes_pooling_layer < 1 || desc->num_nodes_last_layer < 1)
     return fail(nullptr, XV_ERR_INVALID, "xv_create: non-positive layer width");
-  if (desc->precision != XV_PREC_F32 && desc->precision != XV_PREC_BF16X3 && desc->precision != XV_PREC_F16X3)
+  if (desc->precision != XV_PREC_F32 && desc->precision != XV_PREC_BF16X3 && desc->precision != XV_PREC_F16X3 &&
+      desc->precision != XV_PREC_F16F6)
     return fail(nullptr, XV_ERR_INVALID, "xv_create: unknown precision %d", desc->precision);
   if (desc->relu_type < XV_ACT_RELU || desc->relu_type > XV_ACT_PRELU)
     return fail(nullptr, XV_ERR_INVALID, "xv_create: unknown relu_type %d", desc->relu_type);
@@ -847,6 +922,8 @@ int xv_finalize(xv_handle* h) {
       L.im2col = bf && op.in0 == 0;
       L.cin_pad = (L.im2col && L.w <= 9) ? (int)align_up(L.cin, 32) : 0;
       L.use_split = L.im2col || (bf && vin.frame_level && (L.w == 1 || (L.cin % 32 == 0 && L.w <= 9)));   // slab halo of the split kernel
+      L.use_f6 = h->desc.precision == XV_PREC_F16F6 && L.use_split && !L.im2col && L.w >= 4 && L.w <= 8 && L.cin % 32 == 0 &&
+                 L.cout % 4 == 0;
     } else {      // grid convolutions: whole SB blocks per tap; conv0 goes through its own im2col
       L.use_split = bf && (L.mode == 4 || L.cin % 32 == 0);
     }
@@ -1157,6 +1234,8 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       } else if (!L.use_split && op.out != fused_value) {
         st.ksplit = gemm_f32_ksplit(st.M, L.Kpad, L.Npad);
         if (st.ksplit > 1) scratch = (int64_t)st.ksplit * st.M * L.Npad * 4;
+      } else if (L.use_f6) {
+        scratch = (st.rows_in + kSlackRows) * (int64_t)sb_ld(L.cin) * 4;      // the input in the block format of gemm_f16f6.hip
       } else if (L.use_split && L.mode == 0 && op.out != fused_value && op.in1 <= 0 && h->opt_tail_split &&
                  order[s] != key_prod && order[s] != val_prod) {
         scratch = gemm_bf16x3_tail_plan(st.M, L.Kpad, L.Npad, L.w, &st.tail_mt, &st.ksplit);
@@ -1408,7 +1487,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
   const int32_t* off = static_cast<const int32_t*>(p->d_offsets.p);
   const xv_model_desc& d = h->desc;
   const bool split = d.precision != XV_PREC_F32;
-  const int f16 = d.precision == XV_PREC_F16X3;
+  const int f16 = d.precision == XV_PREC_F16X3 || d.precision == XV_PREC_F16F6;
 
   bool prof = false;
   size_t prof_base = 0;
@@ -1570,6 +1649,16 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           a.cin = a.K;
           a.Wsb = L.wsb.p; a.Wfr = L.wfr.p;
           XV_HIP(h, launch_gemm_bf16x3(a, s));
+          break;
+        }
+        if (L.use_f6) {                     // two-unit split: convert the split-blocked input, then the f16 + fp6 kernel
+          if (st.in0_sb_off < 0 || st.scratch_off < 0) return fail(h, XV_ERR_STATE, "f16f6 layer %s has no input / scratch", L.kernel_name.c_str());
+          XV_HIP(h, launch_f6_from_sb(ws + st.in0_sb_off, ws + st.scratch_off, st.rows_in, sb_ld(L.cin) / 32, s));
+          a.Xsb = ws + st.scratch_off;
+          a.ldsbx = sb_ld(L.cin);
+          a.Wfr = L.wf6m.p;
+          a.Wx6 = L.wf6x.p;
+          XV_HIP(h, launch_gemm_f16f6(a, s));
           break;
         }
         if (L.use_split) {

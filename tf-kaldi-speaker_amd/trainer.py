@@ -18,9 +18,11 @@ import numpy as np
 from . import _lib
 from . import model_io
 
-_PRECISIONS = {"f32": _lib.XV_PREC_F32, "bf16x3": _lib.XV_PREC_BF16X3, "f16x3": _lib.XV_PREC_F16X3}
+_PRECISIONS = {"f32": _lib.XV_PREC_F32, "bf16x3": _lib.XV_PREC_BF16X3, "f16x3": _lib.XV_PREC_F16X3, "f16f6": _lib.XV_PREC_F16F6}
+_F16_RANGE = ("f16x3", "f16f6")       # precisions whose activations must stay within the fp16 range
 # "bf16x3": split-precision MFMA over the full fp32 range, ~2e-6 rel-L2 on the x-vector (bar 1e-4);
-# "f16x3": the same kernels on fp16 hi/lo halves, ~3e-7, inputs / activations must stay within +-65504; "f32": exact fp32 MFMA
+# "f16x3": the same kernels on fp16 hi/lo halves, ~3e-7, inputs / activations must stay within +-65504; "f32": exact fp32 MFMA;
+# "f16f6": f16x3 with the multi-tap convolutions on the two-unit split (f16 hi*hi + block-scaled fp6 cross terms), ~1e-5
 DEFAULT_PRECISION = "bf16x3"
 
 
@@ -348,14 +350,14 @@ class Trainer(object):
     def check_overflow(self):
         """f16x3 only: True if a feature or activation went beyond the fp16 range (+-65504) in a forward since the
         last check (xv_check_overflow; synchronous -- call after the results have been fetched)."""
-        if self._precision != "f16x3" or self._h is None:
+        if self._precision not in _F16_RANGE or self._h is None:
             return False
         return _lib.check(self._lib.xv_check_overflow(self._h, 1), self._h) == 1
 
     def _checked(self, emb):
         """Host copies of f16x3 results are range-checked, so that an overflow fails loudly instead of writing wrong
         vectors into an ark (ReLU turns the NaNs an overflow produces into zeros: the output itself can look finite)."""
-        if self.check_overflow() or (self._precision == "f16x3" and not np.isfinite(emb).all()):
+        if self.check_overflow() or (self._precision in _F16_RANGE and not np.isfinite(emb).all()):
             raise FloatingPointError("the f16x3 path converted a value beyond the fp16 range (+-65504): an input feature or an "
                                      "activation is too large; run with precision 'bf16x3' (full fp32 range) or 'f32'")
         return emb
