@@ -42,6 +42,8 @@ struct GemmArgs {
   const void* Wsb;        // packed weights in SB format [Npad][Kpad/32][128 bytes]
   const void* Wfr = nullptr;   // weights, MFMA-fragment-major (gemm_bf16x3_wreg_kernel)
   const void* Wx6 = nullptr;   // XV_PREC_F16F6 layers: block-scaled fp6 cross-term weights (gemm_f16f6.hip; Wfr then holds the f16 main weights)
+  int ysb_f6 = 0;              // gemm_f16f6 kernel: write Ysb in ITS activation block format (f16 hi | fp6 hi / lo codes | scales) -- the
+                               // consumer is another two-unit layer and no conversion pass is needed
   int slab3 = 1;               // one-tap layers: three slab buffers / slabs two steps ahead (gemm_bf16x3_w1p3_kernel); 0 = the
                                // two-buffer kernel (same arithmetic, bit-identical results; xv_set_option "slab3")
   int* ovf = nullptr;          // f16 only: set to 1 when a value beyond the fp16 range was converted (checked by the host)
@@ -126,6 +128,8 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s);
 // split-blocked f16 rows -> the activation block format of gemm_f16f6.hip (same 128 bytes per (row, 32 channels))
 hipError_t launch_f6_from_sb(const void* sb, void* out, int64_t rows, int nblk, hipStream_t s);
+// fp32 feature rows [rows, ldx] (cin <= 32 * nblk real channels) -> the same block format, channels beyond cin zero
+hipError_t launch_f6_from_f32(const float* x, int64_t ldx, int cin, int64_t rows, void* out, int nblk, int* ovf, hipStream_t s);
 
 // rowmap for a valid convolution of width w over packed utterances:
 //   in_off[b] = off0[b] - b*ctx_in  (rows of utterance b in the layer's input)
