@@ -257,6 +257,11 @@ def test_f16f6_two_unit_split(net):
             ("tdnn2_conv", "tdnn2_bn", "tdnn2_relu", "tdnn3_relu", emb)
     tr = _trainer(params, weights, 30, "f16f6")
     got = _run_nodes(tr, feats, offs, nodes)            # _run_nodes also checks bit-identical repetition
+    # the zero-weight taps of a scaled MFMA read up to seven rows behind the last input row: with the workspace full of 0xFF
+    # (an E8M0 scale byte of 255 is a NaN, and NaN x 0 = NaN) the result must not change
+    tr._ws.fill_(255)
+    again = tr.predict_packed(feats, offs, emb).cpu().numpy().astype(np.float64)
+    assert np.array_equal(again, got[emb]), net
     tr.close()
     tr = _trainer(params, weights, 30, "f32")
     exact = _run_nodes(tr, feats, offs, nodes)

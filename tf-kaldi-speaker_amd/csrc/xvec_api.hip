@@ -1657,6 +1657,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           if (L.cin_pad && L.use_f6) {       // two-unit split: the feature rows staged directly in its block format
             XV_HIP(h, launch_f6_from_f32(feats, feat_ld, L.cin, st.rows_in, ws + st.scratch_off, L.cin_pad / 32, static_cast<int*>(h->ovf_flag.p), s));
             a.Xsb = ws + st.scratch_off;
+            XV_HIP(h, hipMemsetAsync(ws + st.scratch_off + st.rows_in * (int64_t)L.cin_pad * 4, 0, (size_t)8 * L.cin_pad * 4, s));
             a.ldsbx = L.cin_pad;
             a.cin = L.cin_pad;
             a.K = L.w * L.cin_pad;
@@ -1696,6 +1697,10 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
             a.Xsb = ws + st.scratch_off;
           }
           a.ysb_f6 = st.out_f6 ? 1 : 0;
+          // taps w .. 7 of a scaled MFMA have zero weights but still read rows m + w .. m + 7: behind the last input row that is
+          // whatever the buffer held, and an E8M0 scale byte of 255 there is a NaN (NaN x 0 = NaN) -- keep eight rows defined
+          XV_HIP(h, hipMemsetAsync(const_cast<char*>(static_cast<const char*>(a.Xsb)) + st.rows_in * (int64_t)sb_ld(L.cin) * 4, 0,
+                                   (size_t)8 * sb_ld(L.cin) * 4, s));
           a.ldsbx = sb_ld(L.cin);
           a.Wfr = L.wf6m.p;
           a.Wx6 = L.wf6x.p;

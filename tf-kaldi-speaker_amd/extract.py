@@ -42,7 +42,7 @@ def build_parser():
     parser.add_argument("--node", type=str, default="", help="The node to output the embeddings.")
     parser.add_argument("--batch-frames", type=int, default=76800,
                         help="Frames packed into one device batch (extension; 76800 = 256 utterances x 300 frames).")
-    parser.add_argument("--precision", type=str, default="", help="f32 | bf16x3 | f16x3 (extension; default: library default)")
+    parser.add_argument("--precision", type=str, default="", help="f32 | bf16x3 | f16x3 | f16f6 (extension; default: library default)")
     parser.add_argument("--scp-input", action="store_true",
                         help="Accept `scp:<file>` as the rspecifier and read its records natively by seeking (extension; "
                              "the reference refuses scp input, extract.py:59-61, because Kaldi binaries expand it upstream).")

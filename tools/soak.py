@@ -19,7 +19,8 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     every = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     params = dict(synth.TDNN_STAT_PARAMS)
-    tr = Trainer(Params(**params), None, 30, single_cpu=True, device=0, precision="bf16x3")
+    precision = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
+    tr = Trainer(Params(**params), None, 30, single_cpu=True, device=0, precision=precision)
     tr.build("predict")
     tr.load_weights(synth.synth_weights(params, 30, seed=0))
     B, T = 256, 300

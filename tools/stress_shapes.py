@@ -24,6 +24,7 @@ def make(params, dim, precision, weights):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    fast_precision = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
     rng = np.random.default_rng(seed)
     nets = {
         "tdnn_stat": (dict(synth.TDNN_STAT_PARAMS), 30, 15),
@@ -34,7 +35,7 @@ def main():
     models = {}
     for name, (params, dim, tmin) in nets.items():
         w = synth.synth_resnet_weights(params, seed=1) if name == "resnet18" else synth.synth_weights(params, dim, seed=1)
-        models[name] = (make(params, dim, "bf16x3", w), make(params, dim, "f32", w), dim, tmin)
+        models[name] = (make(params, dim, fast_precision, w), make(params, dim, "f32", w), dim, tmin)
     worst, t0 = 0.0, time.time()
     for c in range(cases):
         name = list(nets)[c % len(nets)]
