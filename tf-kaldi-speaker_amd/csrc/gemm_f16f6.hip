@@ -58,6 +58,8 @@ __device__ __forceinline__ float e8m0_of(float amax, uint32_t& byte) {
   return __uint_as_float((uint32_t)(127 - e) << 23);
 }
 
+}  // namespace
+
 // split-blocked f16 rows (hi | lo halves) -> the block format above; one thread per (row, 32-channel block)
 __global__ void f6_from_sb_kernel(const char* __restrict__ sb, char* __restrict__ out, int64_t rows, int nblk) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -457,8 +459,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f16f6_kernel(GemmArgs p, int nMt,
   if (p.ysb_f6 && p.Ysb && !p.Y) store_wave_tile_n32_f6(p, acc, m0, n0 + wave * 32, lane_e, wave, smem6);
   else store_wave_tile_n32<64, true>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem6);
 }
-
-}  // namespace
 
 hipError_t launch_f6_from_sb(const void* sb, void* out, int64_t rows, int nblk, hipStream_t s) {
   const int64_t total = rows * nblk;

@@ -6,11 +6,15 @@ out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 step() { echo "$(date +%T) $*" >> $out/progress.txt; }
-step bench; python bench.py > $out/bench_bf16x3.json 2> $out/bench_bf16x3.err
+step bench; python bench.py > $out/bench_f16f6.json 2> $out/bench_f16f6.err      # the default line: TDNN family in f16f6
+step bf16x3; python bench.py --precision bf16x3 --cpu-seconds 0 > $out/bench_bf16x3.json 2> $out/bench_bf16x3.err
 step f32; python bench.py --precision f32 --cpu-seconds 0 --no-extra > $out/bench_f32.json 2> $out/bench_f32.err
-step att; python bench.py --pooling self_attention --cpu-seconds 0 --no-extra > $out/bench_att_bf16x3.json 2> $out/bench_att.err
-step varlen; python bench.py --varlen --cpu-seconds 0 --no-extra > $out/bench_varlen_bf16x3.json 2> $out/bench_varlen.err
+step att; python bench.py --pooling self_attention --cpu-seconds 0 --no-extra > $out/bench_att_f16f6.json 2> $out/bench_att.err
+python bench.py --pooling self_attention --precision bf16x3 --cpu-seconds 0 --no-extra > $out/bench_att_bf16x3.json 2>> $out/bench_att.err
+step varlen; python bench.py --varlen --cpu-seconds 0 --no-extra > $out/bench_varlen_f16f6.json 2> $out/bench_varlen.err
+python bench.py --varlen --precision bf16x3 --cpu-seconds 0 --no-extra > $out/bench_varlen_bf16x3.json 2>> $out/bench_varlen.err
 step etdnn; python bench.py --network extended_tdnn --cpu-seconds 0 --no-extra > $out/bench_etdnn_bf16x3.json 2> $out/bench_etdnn.err
+python bench.py --network extended_tdnn --precision f16f6 --cpu-seconds 0 --no-extra > $out/bench_etdnn_f16f6.json 2>> $out/bench_etdnn.err
 step resnet; python bench.py --network resnet_18 --batch 64 --dim 40 --cpu-seconds 4 --no-extra > $out/bench_resnet18_bf16x3.json 2> $out/bench_resnet.err
 step f16; python bench.py --precision f16x3 --cpu-seconds 0 --no-extra > $out/bench_f16x3.json 2> $out/bench_f16x3.err
 step att_f16; python bench.py --pooling self_attention --precision f16x3 --cpu-seconds 0 --no-extra > $out/bench_att_f16x3.json 2> $out/bench_att_f16.err
@@ -37,7 +41,7 @@ python profiles/summarize_trace.py $(find $out/trace -name "*kernel_trace.csv" |
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 for c in sq fetch write; do python profiles/summarize_pmc.py $(find $out/pmc_$c -name "*counter_collection.csv" | head -1) > $out/pmc_${c}_summary.txt 2>&1; done
 rocm-smi --showproductname > $out/device.txt 2>&1
-python profiles/make_traffic.py $out >> $out/progress.txt 2>&1
+python profiles/make_traffic.py $out f16f6 >> $out/progress.txt 2>&1
 rm -rf $out/trace $out/pmc_sq $out/pmc_fetch $out/pmc_write
 step done
-cat $out/progress.txt; head -c 600 $out/bench_bf16x3.json
+cat $out/progress.txt; head -c 600 $out/bench_f16f6.json
