@@ -32,7 +32,7 @@
 #include <cstdlib>
 #include <mutex>
 
-#include "xv_epilogue.h"
+#include "xv_f6.h"
 
 namespace xv {
 
@@ -556,7 +556,8 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
   // loop, where they would cost registers (and spill) for its whole duration
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
-  if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
+  if constexpr (EPI == 3) store_wave_tile_n32_f6(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);      // XV_PREC_F16F6 producer
+  else if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
   else store_wave_tile_n32<64, F16>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
   stamp(3);
 }
@@ -909,7 +910,7 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
           reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 1, false>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 2, false>),
           reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1, 0, true>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 0, true>),
           reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 1, true>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 2, true>),
-};
+          reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1, 3, true>)};
       hipError_t r = hipSuccess;
       for (const void* k : kernels) {
         r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
@@ -999,6 +1000,11 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
   // whole tiles, then (tail form) the K-split slices of the tail tiles in the same launch
   const int S = tail ? a.ksplit : 0;
   const dim3 grid2(nMain * nNt + (tail ? a.tail_mt * nNt * a.ksplit : 0));
+  if (a.ysb_f6) {                               // XV_PREC_F16F6: this layer's only reader is a two-unit layer -> its block format
+    if (!a.f16 || w < 5 || tail || !a.Ysb || a.Y || a.R || a.pool_part) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 3, true>), grid2, block, smemw32, s, a, nMain, nNt, w, 0);
+    return hipGetLastError();
+  }
   if (w >= 5) {
     if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 0, true>), grid2, block, smemw32, s, a, nMain, nNt, w, S);
     else       hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 0, false>), grid2, block, smemw32, s, a, nMain, nNt, w, S);

@@ -23,7 +23,7 @@
 // loads were issued a whole pass earlier); 246 VGPRs, two workgroups per CU.
 #include <mutex>
 
-#include "xv_epilogue.h"
+#include "xv_f6.h"
 
 namespace xv {
 
@@ -36,27 +36,6 @@ typedef __attribute__((address_space(3))) void* lptr6_t;
 
 constexpr int F6_BM = 128, F6_BN = 128, F6_DROW = 128, F6_DA_ROWS = 136, F6_DA_BYTES = F6_DA_ROWS * F6_DROW;
 constexpr int64_t kWmainCt = 64 * 16, kWxCt = 64 * 16 * 3 + 64 * 4;
-
-// e2m3 code (6 bits) of x * inv, |x * inv| <= 7.5: sign | 2-bit exponent (bias 1) | 3-bit mantissa; exponent field 0 = subnormal
-// (steps of 1/8).  Values below 1 go through 1 + v so that one integer path rounds both ranges (round half up; carries walk into
-// the exponent field by themselves).
-__device__ __forceinline__ uint32_t e2m3_code(float x, float inv) {
-  float v = fminf(fabsf(x) * inv, 7.5f);
-  const bool sub = v < 1.f;
-  const float t = sub ? v + 1.f : v;
-  uint32_t c = ((__float_as_uint(t) + 0x80000u) >> 20) - (126u << 3) - (sub ? 8u : 0u);
-  c = c > 31u ? 31u : c;
-  return c | (x < 0.f ? 32u : 0u);
-}
-// scale of a block whose largest magnitude is amax: smallest e with amax * 2^-e <= 7.5; returns 2^-e, E8M0 byte in `byte`
-__device__ __forceinline__ float e8m0_of(float amax, uint32_t& byte) {
-  if (!(amax > 0.f)) { byte = 0; return 1.f; }
-  const float r = amax * (1.f / 7.5f);
-  int e = (int)((__float_as_uint(r) + 0x7FFFFFu) >> 23) - 127;          // ceil(log2 r)
-  e = e < -126 ? -126 : (e > 126 ? 126 : e);
-  byte = (uint32_t)(127 + e);
-  return __uint_as_float((uint32_t)(127 - e) << 23);
-}
 
 }  // namespace
 
@@ -101,173 +80,6 @@ __global__ void f6_from_sb_kernel(const char* __restrict__ sb, char* __restrict_
   dst[5] = uint4{cl[0], cl[1], cl[2], cl[3]};
   dst[6] = uint4{ch[4], ch[5], cl[4], cl[5]};
   dst[7] = uint4{bh | (bl << 8), 0u, 0u, 0u};
-}
-
-// Epilogue that writes the output in the activation block format above (the consumer is another two-unit layer): BN scale / shift +
-// activation as usual, the 64 x 32 fp32 values of a pass staged row-major in the wave's LDS scratch, then ONE ROW PER LANE: the
-// lane reads its row's 32 channels, takes hi = rn_f16(x), lo = x - hi, the two block maxima, and packs the fp6 codes with the
-// hardware converters (v_cvt_scalef32_pk32_fp6_f16 for hi: codes in element order, x / scale, RNE, saturating;
-// v_cvt_scalef32_2xpk16_fp6_f32 for lo: code 2i from the first operand, 2i + 1 from the second -- tools/proto/cvt_fp6_probe.hip),
-// writes the finished 128-byte block back over its row, and the usual row-contiguous 16-byte stores (row map applied) follow.
-typedef _Float16 v32h_t __attribute__((ext_vector_type(32)));
-typedef float v16f_t __attribute__((ext_vector_type(16)));
-typedef unsigned v6u_t __attribute__((ext_vector_type(6)));
-
-__device__ __forceinline__ void store_wave_tile_n32_f6(const GemmArgs& p, const f32x4 (&acc)[8][2], int mbase, int nbase, int lane,
-                                                       int wave, char* lds) {
-  constexpr int ROWS = 64, NPASS = 2, FPP = 4;
-  const int c16 = lane & 15, g4 = lane >> 4;
-  char* scratch = lds + wave * (ROWS * 128);
-  const int rrow = lane >> 3, rchunk = lane & 7;
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  uint32_t bad = 0;
-  f32x4 sc[2], sh[2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int n4 = nbase + 16 * ct + 4 * g4;
-    const bool ok = n4 < p.N;
-    sc[ct] = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
-    sh[ct] = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
-  }
-  int rmap[NPASS][ROWS / 8];
-#pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-    for (int it = 0; it < ROWS / 8; ++it) {
-      const int m = mbase + ps * ROWS + it * 8 + rrow;
-      rmap[ps][it] = m < p.M ? (p.rowmap ? p.rowmap[m] : m) : -1;
-    }
-  const bool blk_ok = nbase < p.ldsb;
-#pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-#pragma unroll
-    for (int fl = 0; fl < FPP; ++fl)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        f32x4 al = z;
-        if (p.act == ACT_PRELU && p.alpha && nbase + 16 * ct + 4 * g4 < p.N) al = *reinterpret_cast<const f32x4*>(p.alpha + nbase + 16 * ct + 4 * g4);
-        const f32x4& t = acc[ps * FPP + fl][ct];
-        f32x4 v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = apply_act(fmaf(t[i], sc[ct][i], sh[ct][i]), p.act, al[i]);
-        const int row = fl * 16 + c16;
-        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ (row & 7)) << 4)) = v;
-      }
-    wave_lds_sync();
-    {   // one row per lane
-      char* rp = scratch + lane * 128;
-      const int sw = lane & 7;
-      float x[32];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(rp + ((q ^ sw) << 4));
-        x[4 * q] = v[0]; x[4 * q + 1] = v[1]; x[4 * q + 2] = v[2]; x[4 * q + 3] = v[3];
-      }
-      v32h_t hv;
-      v16f_t la, lb;
-      float mh = 0.f, ml = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const _Float16 h0 = (_Float16)x[2 * i], h1 = (_Float16)x[2 * i + 1];
-        hv[2 * i] = h0; hv[2 * i + 1] = h1;
-        const float f0 = (float)h0, f1 = (float)h1;
-        la[i] = x[2 * i] - f0; lb[i] = x[2 * i + 1] - f1;
-        mh = fmaxf(mh, fmaxf(fabsf(f0), fabsf(f1)));
-        ml = fmaxf(ml, fmaxf(fabsf(la[i]), fabsf(lb[i])));
-      }
-      uint32_t bh, bl;
-      (void)e8m0_of(mh, bh);
-      (void)e8m0_of(ml, bl);
-      const float sh_f = bh ? __uint_as_float(bh << 23) : 1.f, sl_f = bl ? __uint_as_float(bl << 23) : 1.f;
-      const v6u_t ch = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hv, sh_f);
-      const v6u_t cl = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(la, lb, sl_f);
-      uint32_t hw[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const f16x2_t pr = {hv[2 * i], hv[2 * i + 1]};
-        hw[i] = __builtin_bit_cast(uint32_t, pr);
-      }
-      if (mbase + ps * ROWS + lane < p.M) {              // rows past M hold whatever the slack behind the input held
-#pragma unroll
-        for (int i = 0; i < 16; ++i) ovf_bits(bad, hw[i]);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<uint4*>(rp + ((q ^ sw) << 4)) = uint4{hw[4 * q], hw[4 * q + 1], hw[4 * q + 2], hw[4 * q + 3]};
-      *reinterpret_cast<uint4*>(rp + ((4 ^ sw) << 4)) = uint4{ch[0], ch[1], ch[2], ch[3]};
-      *reinterpret_cast<uint4*>(rp + ((5 ^ sw) << 4)) = uint4{cl[0], cl[1], cl[2], cl[3]};
-      *reinterpret_cast<uint4*>(rp + ((6 ^ sw) << 4)) = uint4{ch[4], ch[5], cl[4], cl[5]};
-      *reinterpret_cast<uint4*>(rp + ((7 ^ sw) << 4)) = uint4{bh | (bl << 8), 0u, 0u, 0u};
-    }
-    wave_lds_sync();
-#pragma unroll 4
-    for (int it = 0; it < ROWS / 8; ++it) {
-      const int row = it * 8 + rrow;
-      f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
-      int r = rmap[ps][it];
-      const bool zero = r < -1;
-      r = zero ? -r - 2 : r;
-      if (zero) v = z;
-      if (r >= 0 && blk_ok)
-        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)r * p.ldsb * 4 + (nbase >> 5) * 128 + rchunk * 16) = v;
-    }
-    wave_lds_sync();
-  }
-  ovf_report_bits(p.ovf, bad);
-}
-
-// 32 fp32 values of one (row, block) -> the 128-byte block (hardware converters; shared by the feature staging below)
-__device__ __forceinline__ void f6_block_from_f32(const float (&x)[32], uint4 (&blk)[8], uint32_t& bad) {
-  v32h_t hv;
-  v16f_t la, lb;
-  float mh = 0.f, ml = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const _Float16 h0 = (_Float16)x[2 * i], h1 = (_Float16)x[2 * i + 1];
-    hv[2 * i] = h0; hv[2 * i + 1] = h1;
-    const float f0 = (float)h0, f1 = (float)h1;
-    la[i] = x[2 * i] - f0; lb[i] = x[2 * i + 1] - f1;
-    mh = fmaxf(mh, fmaxf(fabsf(f0), fabsf(f1)));
-    ml = fmaxf(ml, fmaxf(fabsf(la[i]), fabsf(lb[i])));
-  }
-  uint32_t bh, bl;
-  (void)e8m0_of(mh, bh);
-  (void)e8m0_of(ml, bl);
-  const float sh_f = bh ? __uint_as_float(bh << 23) : 1.f, sl_f = bl ? __uint_as_float(bl << 23) : 1.f;
-  const v6u_t ch = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hv, sh_f);
-  const v6u_t cl = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(la, lb, sl_f);
-  uint32_t hw[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const f16x2_t pr = {hv[2 * i], hv[2 * i + 1]};
-    hw[i] = __builtin_bit_cast(uint32_t, pr);
-    ovf_bits(bad, hw[i]);
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) blk[q] = uint4{hw[4 * q], hw[4 * q + 1], hw[4 * q + 2], hw[4 * q + 3]};
-  blk[4] = uint4{ch[0], ch[1], ch[2], ch[3]};
-  blk[5] = uint4{cl[0], cl[1], cl[2], cl[3]};
-  blk[6] = uint4{ch[4], ch[5], cl[4], cl[5]};
-  blk[7] = uint4{bh | (bl << 8), 0u, 0u, 0u};
-}
-
-// feature rows (fp32, cin real channels) -> blocks; one thread per (row, block)
-__global__ void f6_from_f32_kernel(const float* __restrict__ x, int64_t ldx, int cin, int64_t rows, char* __restrict__ out, int nblk,
-                                   int* __restrict__ ovf) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * nblk) return;
-  const int64_t r = i / nblk;
-  const int b = (int)(i - r * nblk);
-  float v[32];
-#pragma unroll
-  for (int k = 0; k < 32; ++k) v[k] = (b * 32 + k < cin) ? x[r * ldx + b * 32 + k] : 0.f;
-  uint4 blk[8];
-  uint32_t bad = 0;
-  f6_block_from_f32(v, blk, bad);
-  ovf_report_bits(ovf, bad);
-  uint4* dst = reinterpret_cast<uint4*>(out + i * 128);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) dst[q] = blk[q];
 }
 
 #define XV6_GLD16(dst, ptr, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(dst) : "v"(ptr))
@@ -465,14 +277,6 @@ hipError_t launch_f6_from_sb(const void* sb, void* out, int64_t rows, int nblk, 
   if (total <= 0) return hipSuccess;
   hipLaunchKernelGGL(f6_from_sb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const char*>(sb),
                      static_cast<char*>(out), rows, nblk);
-  return hipGetLastError();
-}
-
-hipError_t launch_f6_from_f32(const float* x, int64_t ldx, int cin, int64_t rows, void* out, int nblk, int* ovf, hipStream_t s) {
-  const int64_t total = rows * nblk;
-  if (total <= 0) return hipSuccess;
-  hipLaunchKernelGGL(f6_from_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, cin, rows, static_cast<char*>(out),
-                     nblk, ovf);
   return hipGetLastError();
 }
 

@@ -128,8 +128,6 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s);
 // split-blocked f16 rows -> the activation block format of gemm_f16f6.hip (same 128 bytes per (row, 32 channels))
 hipError_t launch_f6_from_sb(const void* sb, void* out, int64_t rows, int nblk, hipStream_t s);
-// fp32 feature rows [rows, ldx] (cin <= 32 * nblk real channels) -> the same block format, channels beyond cin zero
-hipError_t launch_f6_from_f32(const float* x, int64_t ldx, int cin, int64_t rows, void* out, int nblk, int* ovf, hipStream_t s);
 
 // rowmap for a valid convolution of width w over packed utterances:
 //   in_off[b] = off0[b] - b*ctx_in  (rows of utterance b in the layer's input)

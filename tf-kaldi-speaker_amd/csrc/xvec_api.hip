@@ -783,7 +783,7 @@ int upload_layer(xv_handle* h, Layer& L) {
       //   main  [Npad/32][cin/32][8 taps][2 channel tiles][64 lanes = 16 * k-chunk + channel][8 x f16]
       //   cross [Npad/32][cin/32][2 macro steps][2 channel tiles] x { 64 x 16 B q6(hi) | 64 x 16 B q6(lo) | 64 x (8 B hi tail | 8 B lo
       //         tail) | 64 x 4 B scales (byte 0 hi, byte 1 lo) },  lane = 16 * (tap & 3) + channel: K group = tap inside the macro step
-      const int ncb = (L.cin_pad ? L.cin_pad : L.cin) / 32;      // first layer: one block per frame, channels >= cin are zero
+      const int ncb = L.cin / 32;
       const size_t main_ct = 64 * 16, cross_ct = 64 * 16 * 3 + 64 * 4;
       std::vector<unsigned char> wm((size_t)(L.Npad / 32) * ncb * 8 * 2 * main_ct, 0), wx((size_t)(L.Npad / 32) * ncb * 2 * 2 * cross_ct, 0);
       for (int n = 0; n < L.Npad; ++n) {
@@ -793,7 +793,7 @@ int upload_layer(xv_handle* h, Layer& L) {
             float whi[32], wlo[32];
             uint16_t hh[32];
             for (int t = 0; t < 32; ++t) {
-              const float wv = (j < L.w && n < N && cb * 32 + t < L.cin) ? W[((size_t)j * L.cin + cb * 32 + t) * N + n] * wscale : 0.f;
+              const float wv = (j < L.w && n < N) ? W[((size_t)j * L.cin + cb * 32 + t) * N + n] * wscale : 0.f;
               hh[t] = f32_to_f16_rn(wv);
               whi[t] = f16_to_f32(hh[t]);
               wlo[t] = wv - whi[t];
@@ -924,9 +924,10 @@ int xv_finalize(xv_handle* h) {
       L.im2col = bf && op.in0 == 0;
       L.cin_pad = (L.im2col && L.w <= 9) ? (int)align_up(L.cin, 32) : 0;
       L.use_split = L.im2col || (bf && vin.frame_level && (L.w == 1 || (L.cin % 32 == 0 && L.w <= 9)));   // slab halo of the split kernel
-      // two-unit split: 4..8 taps over whole 32-channel blocks -- also the first layer, whose frames are staged as one padded block
-      L.use_f6 = h->desc.precision == XV_PREC_F16F6 && L.use_split && L.w >= 4 && L.w <= 8 && L.cout % 4 == 0 &&
-                 (L.im2col ? L.cin_pad > 0 : L.cin % 32 == 0);
+      // two-unit split: 4..8 taps over whole 32-channel blocks (the first layer, K = 5 x 30, stays on the f16 kernel and writes
+      // the block format of its reader: gemm_bf16x3_w14p2_kernel<1, 3, true>)
+      L.use_f6 = h->desc.precision == XV_PREC_F16F6 && L.use_split && !L.im2col && L.w >= 4 && L.w <= 8 && L.cin % 32 == 0 &&
+                 L.cout % 4 == 0;
     } else {      // grid convolutions: whole SB blocks per tap; conv0 goes through its own im2col
       L.use_split = bf && (L.mode == 4 || L.cin % 32 == 0);
     }
@@ -1359,8 +1360,15 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     const Op& pop = h->ops[prod->op];
     if (pop.kind != OP_GEMM) continue;
     const Layer& PL = h->layers[pop.layer];
-    if (!PL.use_f6 || prod->to_out || prod->out_off >= 0 || prod->out_sb_off < 0 || prod->stage != PL.final_stage() || pop.in1 > 0) continue;
+    // producers that can write the format: another two-unit layer, or a >= 5-tap layer of the f16 kernel (its <1, 3, true> form;
+    // no K-split tail there: the tail's reduce kernel writes split-blocked rows)
+    const bool f16_multitap = PL.mode == 0 && PL.use_split && !PL.use_f6 && PL.w >= 5 && PL.w <= 9 && (PL.im2col ? PL.cin_pad > 0 : PL.cin % 32 == 0) &&
+                              prod->fuse_att == 0 && !prod->fuse_pool;
+    if (!(PL.use_f6 || f16_multitap) || prod->to_out || prod->out_off >= 0 || prod->out_sb_off < 0 || prod->stage != PL.final_stage() ||
+        pop.in1 > 0)
+      continue;
     prod->out_f6 = true;
+    if (f16_multitap) { prod->tail_mt = 0; prod->ksplit = 1; }
     cs.in_f6 = true;
   }
 
@@ -1654,19 +1662,6 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           // 30-dim first layer on the split kernel: materialise the w*cin-wide rows once (SB
           // format, K padded to 32), then it is a dense layer on those rows
           if (st.scratch_off < 0) return fail(h, XV_ERR_STATE, "im2col layer has no scratch");
-          if (L.cin_pad && L.use_f6) {       // two-unit split: the feature rows staged directly in its block format
-            XV_HIP(h, launch_f6_from_f32(feats, feat_ld, L.cin, st.rows_in, ws + st.scratch_off, L.cin_pad / 32, static_cast<int*>(h->ovf_flag.p), s));
-            a.Xsb = ws + st.scratch_off;
-            XV_HIP(h, hipMemsetAsync(ws + st.scratch_off + st.rows_in * (int64_t)L.cin_pad * 4, 0, (size_t)8 * L.cin_pad * 4, s));
-            a.ldsbx = L.cin_pad;
-            a.cin = L.cin_pad;
-            a.K = L.w * L.cin_pad;
-            a.Wfr = L.wf6m.p;
-            a.Wx6 = L.wf6x.p;
-            a.ysb_f6 = st.out_f6 ? 1 : 0;
-            XV_HIP(h, launch_gemm_f16f6(a, s));
-            break;
-          }
           if (L.cin_pad) {
             // the 30-dim feature rows become SB rows of one 32-channel block (9.8 MB for 256 x 300 frames instead of the
             // 48 MB of materialised 5-frame rows); the layer is then an ordinary 5-tap convolution over them
@@ -1677,6 +1672,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
             a.cin = L.cin_pad;
             a.K = L.w * L.cin_pad;
             a.Wsb = L.wsb.p; a.Wfr = L.wfr.p;
+            a.ysb_f6 = st.out_f6 ? 1 : 0;
             XV_HIP(h, launch_gemm_bf16x3(a, s));
             break;
           }
@@ -1712,6 +1708,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           a.Xsb = ws + st.in0_sb_off;
           a.ldsbx = L.mode == 0 ? sb_ld(L.cin) : 0;
           a.Wsb = L.wsb.p; a.Wfr = L.wfr.p;
+          a.ysb_f6 = st.out_f6 ? 1 : 0;
           if (st.tail_mt > 0 && st.scratch_off >= 0) {
             a.tail_mt = st.tail_mt;
             a.ksplit = st.ksplit;
