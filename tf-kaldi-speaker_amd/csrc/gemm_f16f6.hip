@@ -147,6 +147,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f16f6_kernel(GemmArgs p, int nMt,
     if (2 < nt) asm volatile("" : "+v"(Wm[buf][2][0]), "+v"(Wm[buf][2][1]));
     if (3 < nt) asm volatile("" : "+v"(Wm[buf][3][0]), "+v"(Wm[buf][3][1]));
   };
+  // the same, leaving the five youngest operations (the slab pieces issued behind the cross weights) in flight
+  auto wait_keep5 = [&](int buf) __attribute__((always_inline)) {
+    constexpr int NT0 = NTAPS < 4 ? NTAPS : 4;
+    const int nt = buf == 0 ? NT0 : NTAPS - 4;
+    asm volatile("s_waitcnt vmcnt(5)"
+                 : "+v"(Xh[0]), "+v"(Xh[1]), "+v"(Xl[0]), "+v"(Xl[1]), "+v"(Xth[0]), "+v"(Xth[1]), "+v"(Xtl[0]), "+v"(Xtl[1]),
+                   "+v"(Xs[0]), "+v"(Xs[1])
+                 :
+                 : "memory");
+    if (0 < nt) asm volatile("" : "+v"(Wm[buf][0][0]), "+v"(Wm[buf][0][1]));
+    if (1 < nt) asm volatile("" : "+v"(Wm[buf][1][0]), "+v"(Wm[buf][1][1]));
+    if (2 < nt) asm volatile("" : "+v"(Wm[buf][2][0]), "+v"(Wm[buf][2][1]));
+    if (3 < nt) asm volatile("" : "+v"(Wm[buf][3][0]), "+v"(Wm[buf][3][1]));
+  };
   auto load_x = [&](int step) __attribute__((always_inline)) {
     // per channel tile 3 328 bytes: [64 x 16 hi | 64 x 16 lo | 64 x (8 hi tail | 8 lo tail) | 64 x 4 scales]
     const char* p0 = Wx_g + (int64_t)step * 2 * kWxCt + lane * 16;
@@ -182,12 +196,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16f6_kernel(GemmArgs p, int nMt,
       mo[q][j] = r * F6_DROW + ((g4 ^ ((r >> 1) & 7)) << 4);
     }
   }
-  // cross pass: the two block-scaled MFMAs of every tile
+  // cross pass: the two block-scaled MFMAs of every tile.  Four MFMAs (64 cycles) per tile do not cover an LDS read, so the
+  // fragments are read XD - 1 tiles ahead: two where the registers allow it (up to 6 taps), one otherwise
+  constexpr int XD = NTAPS <= 6 ? 4 : 3;
   auto cross_pass = [&](int cb, int q) __attribute__((always_inline)) {
     const char* slab = smem6 + (cb & 1) * F6_DA_BYTES;
-    v4i fh[2], fl[2];
-    v2i fth[2], ftl[2];
-    int fs[2];
+    v4i fh[XD], fl[XD];
+    v2i fth[XD], ftl[XD];
+    int fs[XD];
     auto read_cross = [&](int g, int slot) __attribute__((always_inline)) {
       fh[slot] = *reinterpret_cast<const v4i*>(slab + xo[q][0] + g * 2048);
       fl[slot] = *reinterpret_cast<const v4i*>(slab + xo[q][1] + g * 2048);
@@ -195,11 +211,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16f6_kernel(GemmArgs p, int nMt,
       ftl[slot] = *reinterpret_cast<const v2i*>(slab + xo[q][2] + g * 2048 + 8);
       fs[slot] = *reinterpret_cast<const int*>(slab + xo[q][3] + g * 2048);
     };
-    read_cross(0, 0);
+#pragma unroll
+    for (int g = 0; g < XD - 1; ++g) read_cross(g, g);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-      const int sl = g & 1;
-      if (g + 1 < 8) read_cross(g + 1, sl ^ 1);
+      const int sl = g % XD;
+      if (g + XD - 1 < 8) read_cross(g + XD - 1, (g + XD - 1) % XD);
       const v8i a_hi6 = {fh[sl][0], fh[sl][1], fh[sl][2], fh[sl][3], fth[sl][0], fth[sl][1], 0, 0};
       const v8i a_lo6 = {fl[sl][0], fl[sl][1], fl[sl][2], fl[sl][3], ftl[sl][0], ftl[sl][1], 0, 0};
 #pragma unroll
@@ -239,26 +256,49 @@ __global__ __launch_bounds__(256, 2) void gemm_f16f6_kernel(GemmArgs p, int nMt,
     }
   };
 
+  // the whole next slab goes out in the FIRST macro step of a channel block, behind the cross weights: five pieces per wave (17
+  // groups over 4 waves, the last ones clamped duplicates), so that the wait at the end of that step can leave exactly them in
+  // flight -- they are only needed at the barrier one macro step later
+  auto dma_next = [&](int cb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int g = wave + 4 * i;
+      dma_a(cb + 1 < ncb ? cb + 1 : cb, (cb + 1) & 1, g < 17 ? g : 16);
+    }
+  };
   for (int step = 0; step < nsteps; step += 2) {        // two macro steps = one channel block; main weight buffers alternate statically
     const int cb = step >> 1;
-    // ---- q = 0: main weights of (cb, 1) and the first half of slab cb + 1 go out first
+    // ---- q = 0: main weights of (cb, 1) first; behind the cross pass the cross weights of (cb, 1), then slab cb + 1
+#ifndef XV_F6_NOW      // (timing lab: -DXV_F6_NOW never reloads the main weights -- wrong results)
     load_wm(step + 1, 1);
-    if (cb + 1 < ncb) for (int g = wave; g < 9; g += 4) dma_a(cb + 1, (cb + 1) & 1, g);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     cross_pass(cb, 0);
     __builtin_amdgcn_sched_barrier(0);
-    load_x(step + 1);                                   // cross weights of (cb, 1) land while the main pass runs
+#ifndef XV_F6_NOX      // (timing lab: -DXV_F6_NOX keeps the prologue's cross weights for every step -- wrong results)
+    load_x(step + 1);                                   // land while the main pass runs
+#endif
+#ifndef XV_F6_NOD      // (timing lab: -DXV_F6_NOD stages no slab in the loop -- wrong results)
+    dma_next(cb);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     main_pass(cb, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+#ifndef XV_F6_NOD
+    wait_keep5(1);                                      // weights landed; the five slab pieces may still be in flight
+#else
     wait_all(1);
+#endif
     // ---- q = 1
+#ifndef XV_F6_NOW
     load_wm(step + 2 < nsteps ? step + 2 : 0, 0);
-    if (cb + 1 < ncb) for (int g = 9 + wave; g < 17; g += 4) dma_a(cb + 1, (cb + 1) & 1, g);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     cross_pass(cb, 1);
     __builtin_amdgcn_sched_barrier(0);
+#ifndef XV_F6_NOX
     load_x(step + 2 < nsteps ? step + 2 : 0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     main_pass(cb, 1, 1);
     __builtin_amdgcn_sched_barrier(0);

@@ -17,7 +17,7 @@ from tf_kaldi_speaker_amd.trainer import Trainer  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 params = Params(**dict(synth.TDNN_STAT_PARAMS))
-tr = Trainer(params, None, 30, single_cpu=True, device=0, precision="bf16x3")
+tr = Trainer(params, None, 30, single_cpu=True, device=0, precision=os.environ.get("XVEC_TLAB_PRECISION", "bf16x3"))
 tr.build("predict")
 tr.load_weights(synth.synth_weights(params, 30, seed=0))
 feats = torch.from_numpy(np.concatenate(synth.synth_features(256, 300, 30, seed=1234))).cuda()
