@@ -235,17 +235,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f16f6_kernel(GemmArgs p, int nMt,
     const char* slab = smem6 + (cb & 1) * F6_DA_BYTES;
     constexpr int NT0 = NTAPS < 4 ? NTAPS : 4;
     const int nt_here = q == 0 ? NT0 : NTAPS - 4;          // compile-time after inlining (q is a literal at both call sites)
-    f16x8 fm[2][4];
+    constexpr int MD = NTAPS <= 7 ? 3 : 2;               // fragment slots: read MD - 1 tiles ahead
+    f16x8 fm[MD][4];
     auto read_main = [&](int g, int slot) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (j < nt_here) fm[slot][j] = *reinterpret_cast<const f16x8*>(slab + mo[q][j] + g * 2048);
     };
-    read_main(0, 0);
+#pragma unroll
+    for (int g = 0; g < MD - 1; ++g) read_main(g, g);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-      const int sl = g & 1;
-      if (g + 1 < 8) read_main(g + 1, sl ^ 1);
+      const int sl = g % MD;
+      if (g + MD - 1 < 8) read_main(g + MD - 1, (g + MD - 1) % MD);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (j < nt_here) {
