@@ -6,7 +6,7 @@ Output of the committed version: all layers x3 8.9e-5 (GPU: 7.0e-5); only key1 4
 single layer ~1.3e-5; key0+key1 exact 3.9e-5; a fourth lo*lo product everywhere 4.5e-5; fp32-rounded inputs 3.5e-7."""
 import sys, numpy as np
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ref_numpy
 from tf_kaldi_speaker_amd import synth
 

@@ -6,7 +6,7 @@ bf16 rate): 1 + 2 x 1/2 = 2 MFMA units per product instead of the 3 of bf16x3 / 
 of 300 frames, sums in float64, against the exact float64 forward.  Also prints f16x3 and a one-sided variant for reference."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ref_numpy
 from tf_kaldi_speaker_amd import synth
 

@@ -1,8 +1,8 @@
 """Quick look at the f16f6 precision: conv-layer outputs and the x-vector against the exact fp32 path and the float64 oracle,
-next to f16x3 (ragged batch incl. a 15-frame utterance).  usage: python tools/f6_check.py"""
+next to f16x3 (ragged batch incl. a 15-frame utterance).  usage: python tests/analysis/f6_check.py"""
 import os
 import sys, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tf_kaldi_speaker_amd import synth
 from tf_kaldi_speaker_amd.params import Params

@@ -235,7 +235,7 @@ def test_compact_grid_rows_are_bit_identical_to_the_full_enumeration(kw):
 @pytest.mark.parametrize("net", ["tdnn", "tdnn_narrow", "etdnn"])
 def test_f16f6_two_unit_split(net):
     """XV_PREC_F16F6: the 5- and 7-tap convolutions compute hi*hi in fp16 and the two cross terms on the block-scaled fp6 path
-    (csrc/gemm_f16f6.hip: 1.5 MFMA units per product instead of 3).  tools/f16f8_error_model.py predicts ~1e-5 on the x-vector;
+    (csrc/gemm_f16f6.hip: 1.5 MFMA units per product instead of 3).  tests/analysis/f16f8_error_model.py predicts ~1e-5 on the x-vector;
     the bar is the path's 1e-4 against the float64 oracle, on every stage endpoint of the converted layers (their conv / bn
     stages run through the same kernel with other epilogue vectors) and on the embedding; against the exact fp32 path the
     frame-level layers must stay within 5e-5.  Ragged batch with the shortest possible utterance; narrow variant: 64 channels

@@ -3,7 +3,7 @@
 //   a * w ~ f16(a) * f16(w)                                                   v_mfma_f32_16x16x32_f16
 //         + q6(f16(a)) * q6(w - f16(w)) + q6(a - f16(a)) * q6(f16(w))          2 x v_mfma_scale_f32_16x16x128_f8f6f4
 // with q6 = OCP fp6 e2m3 under one power-of-two (E8M0) scale per 32 channels.  The cross terms are ~2^-11 of the result, so the
-// 3 mantissa bits of e2m3 leave ~1e-5 relative error per layer (bar 1e-4; tools/f16f8_error_model.py), and the block-scaled
+// 3 mantissa bits of e2m3 leave ~1e-5 relative error per layer (bar 1e-4; tests/analysis/f16f8_error_model.py), and the block-scaled
 // instruction runs at four times the f16 rate: a product costs 1 + 2 x 1/4 MFMA units instead of the 3 of bf16x3 / f16x3
 // (tools/mfma_mix_bench.hip: 1.6x at the same tile).
 //

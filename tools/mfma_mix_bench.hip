@@ -5,7 +5,7 @@
 //   mix C           : the same with fp8 e4m3 cross terms
 // (mix B / C hold 56-64 weight registers per K = 128 step: 134-162 VGPRs in this loop, still three workgroups per CU.)
 // Operands stay in registers (variant 0) or the activation-side fragments are re-read from LDS for every frame tile (variant 1), as
-// the product kernel does.  Prints microseconds per K = 128 of one wave-tile set and the ratio.  tools/f16f8_error_model.py has the
+// the product kernel does.  Prints microseconds per K = 128 of one wave-tile set and the ratio.  tests/analysis/f16f8_error_model.py has the
 // accuracy side (1.2e-5 on the TDNN x-vector with e2m3 cross terms; bar 1e-4).
 // build: hipcc -O3 --offload-arch=gfx950 tools/mfma_mix_bench.hip -o tools/mfma_mix_bench.bin
 #include <hip/hip_runtime.h>
