@@ -291,11 +291,10 @@ def main():
               file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # The library default (bf16x3) keeps the full fp32 range.  For the TDNN the bench runs the fastest precision that its own
-    # parity check passes: f16f6 (5- / 7-tap convolutions on the two-unit split, ~2e-6 on the x-vector against the 1e-4 bar; values
-    # beyond the fp16 range are detected and raise).  --precision / XVEC_PRECISION override; the extended TDNN (its 9-tap layer
-    # is not eligible and f16x3 is slower than bf16x3) and the ResNet keep the library default.
-    precision = args.precision or ("f16f6" if args.network == "tdnn" else trainer_mod.DEFAULT_PRECISION)
+    # The bench runs what a default invocation of the library, the CLI and the launcher runs (trainer.default_precision: f16f6 for the
+    # TDNN, bf16x3 for the extended TDNN and the ResNet); --precision / XVEC_PRECISION override.  The default line also carries the
+    # rate of the full-range precision (value_bf16x3).
+    precision = args.precision or trainer_mod.default_precision(args.network)
 
     base = synth.TDNN_ATT_PARAMS if args.pooling == "self_attention" else synth.TDNN_STAT_PARAMS
     if args.network == "resnet_18":
@@ -381,6 +380,24 @@ def main():
         del g2
         tr.release_graphs()                                # the graph is gone: its plan / workspace may be reused
     tdnn_default = args.network == "tdnn" and args.pooling == "statistics_pooling"
+    # the same K-step region in the full-range precision (bf16x3: no fp16 range to guard), for reference beside `value`
+    bf_rate = None
+    if extra and precision != "bf16x3" and not args.graph:
+        tr2 = Trainer(params, None, args.dim, single_cpu=True, device=local_rank, precision="bf16x3")
+        tr2.build("predict")
+        tr2.load_weights(weights)
+        out2 = torch.empty_like(out)
+
+        def step2():
+            tr2.predict_packed(feats, offsets, out=out2)
+
+        for _ in range(args.warmup + 10):
+            step2()
+        sync_dev()
+        el_bf = sharding.timed_steps(step2, args.steps, sync_dev, dist=d, device=red_dev)
+        bf_rate = n_gpus * args.batch * args.steps / el_bf
+        tr2.close()
+        del out2
     c4 = None
     if extra and tdnn_default and args.c4_steps > 0:
         c4 = config4_leg(tr, args, dist, world, rank, dev, weights, params)
@@ -453,6 +470,7 @@ def main():
             result["value_reps"] = {"n": len(rates), "min": round(rates[0], 1), "median": round(rates[len(rates) // 2], 1),
                                     "max": round(rates[-1], 1), "what": "repetitions of the same %d-step timed region" % args.steps}
         result["e2e_value"] = round(e2e_rate, 1) if e2e_rate else None
+        result["value_bf16x3"] = round(bf_rate, 1) if bf_rate else None
         result["config4"] = c4
     tr.close()
     if world > 1:

@@ -39,7 +39,7 @@ def _run(tr, utts, node=None):
     return tr.predict_packed(packed, offsets, node=node).cpu().numpy()
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+@pytest.mark.parametrize("precision", ["bf16x3", "f16f6", "f32"])
 def test_full_batch_determinism_and_batch_invariance(precision):
     from tf_kaldi_speaker_amd import synth
     tr, weights, params = _make(precision)

@@ -45,7 +45,7 @@ def test_random_ragged_batches(seed):
     nutt = int(rng.integers(1, 12))
     lens = [int(x) for x in rng.choice([15, 16, 17, 31, 64, 127, 128, 129, 200, 333], size=nutt)]
     utts = synth.synth_features(nutt, lens, 30, seed=seed + 50)
-    for precision in ("bf16x3", "f16x3", "f32"):
+    for precision in ("bf16x3", "f16x3", "f16f6", "f32"):
         tr = _trainer(params, weights, 30, precision)
         got = tr.predict_list(utts)
         for i, u in enumerate(utts):
@@ -139,7 +139,8 @@ def test_fused_pooling_path_is_taken_at_the_baseline_geometry():
     {"att_num_heads": 3, "att_split_key": False, "att_split_value": False},               # every head pools every channel
     {"att_num_heads": 5, "num_nodes_pooling_layer": 1600, "att_key_num_nodes": [1500, 1600]},   # split heads of 320 channels
 ])
-def test_fused_attention_path_matches_unfused_and_exact(kw):
+@pytest.mark.parametrize("precision", ["bf16x3", "f16f6"])
+def test_fused_attention_path_matches_unfused_and_exact(kw, precision):
     """Attentive pooling with the key / value never stored (score partials in the epilogue of the last key layer,
     weighted moments in the epilogue of the value layer, model/pooling.py:189-217) against the unfused kernels
     (xv_set_option "att_fusion" 0) and against the exact fp32 path, on a ragged batch with several M tiles."""
@@ -153,7 +154,7 @@ def test_fused_attention_path_matches_unfused_and_exact(kw):
     feats = torch.from_numpy(np.concatenate(utts)).cuda()
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     nodes = ("att_output_before_nonlinear", "tdnn6_dense")
-    tr = _trainer(params, weights, 30, "bf16x3")
+    tr = _trainer(params, weights, 30, precision)
     ws_fused = tr.plan_info(offs, "tdnn6_dense")["workspace_bytes"]
     fused = _run_nodes(tr, feats, offs, nodes)
     tr.set_option("att_fusion", 0)
@@ -317,3 +318,90 @@ def test_vmcnt_retires_in_issue_order(tmp_path, repo_root):
     assert len(lines) == 2, r.stdout
     for l in lines:
         assert ": 0 out-of-order" in l, l
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16f6", "bf16x3"])
+@pytest.mark.parametrize("layer,shift", [(2, 10), (4, 10), (3, 14), (1, -9)])
+def test_split_formats_survive_a_rescaled_layer(precision, layer, shift):
+    """The fp16 split (hi + lo, 11 + 11 significand bits) has a lower end too: below 2^-3 the low half is subnormal.  A model
+    whose layer `layer` has its batch-normalisation gamma / beta scaled by 2^-shift and the next layer's kernel by 2^shift
+    computes the same function (ReLU is positively homogeneous; the float64 oracle agrees to rounding) but its activations
+    sit at ~1e-3 (shift 10) or ~6e-5 (shift 14: below the smallest normal fp16 number) -- or at ~500 (shift -9).  The
+    library keeps every layer's split copy at a power-of-two scale derived from gamma / beta (csrc/xvec_api.hip,
+    act_exponent), so all three split precisions must stay at their usual accuracy: 1e-4 is the path's bar, 2e-5 what
+    they deliver on the unscaled model."""
+    from tf_kaldi_speaker_amd import synth
+    params = dict(synth.TDNN_STAT_PARAMS)
+    weights = dict(synth.synth_weights(params, 30, seed=3))
+    f = 2.0 ** -shift
+    for nm in ("gamma", "beta"):
+        weights["tdnn/tdnn%d_bn/%s" % (layer, nm)] = (weights["tdnn/tdnn%d_bn/%s" % (layer, nm)] * f).astype(np.float32)
+    nxt = "tdnn/tdnn%d_%s/kernel" % (layer + 1, "conv" if layer + 1 <= 3 else "dense")
+    weights[nxt] = (weights[nxt] / f).astype(np.float32)
+    lens = [300, 64, 15, 129]
+    utts = synth.synth_features(len(lens), lens, 30, seed=43)
+    base = dict(synth.synth_weights(params, 30, seed=3))
+    tr = _trainer(params, weights, 30, precision)
+    got = tr.predict_list(utts)
+    mid = tr.predict_list(utts[:2], node="tdnn%d_relu" % layer)          # the scaled activations themselves (fp32 endpoint)
+    tr.close()
+    for i, u in enumerate(utts):
+        ref = ref_numpy.predict(u, weights, params, 30)
+        ref0 = ref_numpy.predict(u, base, params, 30)
+        assert _rel(ref, ref0.astype(np.float64)) <= 1e-6                  # the rescaled model is the same function
+        err = _rel(got[i], ref)
+        assert err <= TOL, (precision, layer, shift, i, err)
+        assert err <= 2e-5, (precision, layer, shift, i, err)
+    for i in range(2):
+        ref = ref_numpy.predict(utts[i], weights, params, 30, node="tdnn%d_relu" % layer)
+        assert _rel(mid[i], ref) <= TOL, (precision, layer, shift, i)
+
+
+def test_fp16_split_refuses_features_it_cannot_represent():
+    """Input features are whatever the caller sends (no normalisation in front of them): features so small that every low
+    half of the fp16 split is subnormal (all below 2^-8) are refused with an error in the fp16 precisions -- as features
+    beyond 65504 are -- and are no problem for bf16x3, which has the full fp32 exponent range."""
+    from tf_kaldi_speaker_amd import synth
+    params = dict(synth.TDNN_STAT_PARAMS)
+    weights = synth.synth_weights(params, 30, seed=0)
+    feats = np.stack(synth.synth_features(2, 40, 30, seed=9))
+    tiny = (feats * 2.0 ** -14).astype(np.float32)
+    for prec in ("f16x3", "f16f6"):
+        tr = _trainer(params, weights, 30, prec)
+        with pytest.raises(FloatingPointError, match="below 2\\^-8"):
+            tr.predict(tiny)
+        ok = tr.predict(feats)                                              # the flag was reset: the next batch is fine
+        assert _rel(ok[0], ref_numpy.predict(feats[0], weights, params, 30)) <= TOL
+        tr.close()
+    tr = _trainer(params, weights, 30, "bf16x3")
+    got = tr.predict(tiny)
+    assert _rel(got[1], ref_numpy.predict(tiny[1], weights, params, 30)) <= TOL
+    tr.close()
+
+
+def test_handles_release_their_device_memory():
+    """xv_destroy frees everything xv_finalize uploaded (incl. the two-unit layers' second weight copy and the ResNet's direct
+    conv0 kernel): creating and closing handles in a loop must not eat device memory."""
+    import torch
+    from tf_kaldi_speaker_amd import synth
+    params = dict(synth.TDNN_STAT_PARAMS)
+    weights = synth.synth_weights(params, 30, seed=0)
+    rparams = dict(synth.RESNET_PARAMS)
+    rweights = synth.synth_resnet_weights(rparams, seed=0)
+    feats = np.stack(synth.synth_features(1, 40, 30, seed=1))
+    def cycle():
+        tr = _trainer(params, weights, 30, "f16f6")
+        tr.predict(feats)
+        tr.close()
+        tr = _trainer(rparams, rweights, 40, "f16x3")
+        tr.close()
+    cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, (free0, free1)        # one cycle uploads > 60 MB of weights

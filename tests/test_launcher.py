@@ -249,3 +249,32 @@ def test_run_jobs_serialises_a_slot_and_overlaps_slots(tmp_path):
     el = time.time() - t0
     assert codes == [0, 0, 0, 0] and 0.75 <= el < 1.6
     assert [open(l).read().splitlines()[-1] for l in logs] == ["0", "1", "2", "3"]
+
+
+def test_utterances_without_vad_are_skipped_not_fatal(tmp_path):
+    """select-voiced-frames ark:- scp,s,cs:vad.scp (run_extract_embeddings.sh:47) warns about an utterance that has no VAD
+    decisions and goes on.  Same here: the launcher's shards leave it out, and the job's lock-step lookup returns None for it
+    (the front-end then drops it) without losing its place in the sorted table."""
+    lens = [40, 50, 60, 70, 80]
+    data, feats, vads = make_data_dir(tmp_path, lens)
+    keys = list(feats)
+    lines = open(os.path.join(data, "vad.scp")).read().splitlines()
+    with open(os.path.join(data, "vad.scp"), "w") as f:                 # drop the decisions of the 2nd and the last utterance
+        f.write("\n".join(l for l in lines if l.split()[0] not in (keys[1], keys[4])) + "\n")
+    out = str(tmp_path / "xv")
+    skeys, lengths, shards = run_extract.make_shards(data, out, 2, use_vad=True)
+    assert skeys == [keys[0], keys[2], keys[3]] and list(lengths) == [40, 60, 70]
+    tabs = []
+    for j in (1, 2):
+        ft = [k for k, _ in native_ark.read_scp_table(os.path.join(out, "split2", str(j), "feats.scp"))]
+        assert ft == [k for k, _ in native_ark.read_scp_table(os.path.join(out, "split2", str(j), "vad.scp"))]
+        tabs += ft
+    assert sorted(tabs) == sorted(skeys)
+    look = extract._vad_lookup("scp:" + os.path.join(data, "vad.scp"))
+    got = [look(k) for k in keys]                                          # features of all five arrive at the job
+    assert got[1] is None and got[4] is None
+    for i in (0, 2, 3):
+        np.testing.assert_array_equal(got[i], vads[keys[i]])
+    with pytest.raises(ValueError):                                        # nothing left at all: that is an error
+        open(os.path.join(data, "vad.scp"), "w").write("nobody %s:0\n" % os.path.join(data, "vad.ark"))
+        run_extract.make_shards(data, out, 2, use_vad=True)

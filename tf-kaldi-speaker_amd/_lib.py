@@ -23,11 +23,11 @@ XV_POOL_STATISTICS = 0
 XV_POOL_SELF_ATTENTION = 1
 XV_ACT_RELU, XV_ACT_LRELU, XV_ACT_PRELU = 0, 1, 2
 
-EXPORTS = ["xv_version", "xv_create", "xv_set_tensor", "xv_finalize", "xv_set_option", "xv_check_overflow", "xv_node_id", "xv_node_context",
+EXPORTS = ["xv_version", "xv_create", "xv_set_tensor", "xv_finalize", "xv_set_option", "xv_check_overflow", "xv_flags_async", "xv_flags_decode", "xv_node_id", "xv_node_context",
            "xv_plan_create", "xv_plan_query", "xv_plan_destroy", "xv_forward", "xv_profile_begin", "xv_profile_end",
            "xv_destroy", "xv_last_error",
            "xv_frontend_cmn_select", "xv_length_normalize", "xv_speaker_mean",
-           "xv_ark_open", "xv_ark_open_scp", "xv_ark_scp_count", "xv_ark_scp_shapes", "xv_ark_next_batch", "xv_ark_pending_shape", "xv_ark_skipped", "xv_ark_set_copy_threads", "xv_ark_error", "xv_ark_close", "xv_ark_format_vectors"]
+           "xv_ark_open", "xv_ark_open_scp", "xv_ark_scp_count", "xv_ark_scp_shapes", "xv_ark_next_batch", "xv_ark_pending_shape", "xv_ark_skipped", "xv_ark_set_copy_threads", "xv_ark_error", "xv_ark_close", "xv_ark_format_vectors", "xv_crc32c"]
 
 
 class ModelDesc(C.Structure):
@@ -88,6 +88,8 @@ def load():
     lib.xv_finalize.argtypes = [vp]
     lib.xv_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.xv_check_overflow.argtypes = [vp, i32]
+    lib.xv_flags_async.argtypes = [vp, vp, vp]
+    lib.xv_flags_decode.argtypes = [vp]
     lib.xv_node_id.argtypes = [vp, C.c_char_p]
     lib.xv_node_context.argtypes = [vp, i32]
     lib.xv_plan_create.argtypes = [vp, vp, i32, i32, vp, C.POINTER(vp)]
@@ -118,9 +120,11 @@ def load():
     lib.xv_ark_close.restype = None
     lib.xv_ark_format_vectors.argtypes = [vp, i32, vp, i32, i64, vp, i64]
     lib.xv_ark_format_vectors.restype = i64
+    lib.xv_crc32c.argtypes = [C.c_uint32, vp, i64]
+    lib.xv_crc32c.restype = C.c_uint32
     for n in EXPORTS:
         if n not in ("xv_version", "xv_last_error", "xv_plan_destroy", "xv_destroy", "xv_ark_skipped", "xv_ark_error",
-                     "xv_ark_close", "xv_ark_format_vectors", "xv_ark_scp_count"):
+                     "xv_ark_close", "xv_ark_format_vectors", "xv_ark_scp_count", "xv_crc32c"):
             getattr(lib, n).restype = i32
     _lib = lib
     return lib

@@ -23,6 +23,9 @@
 #include <thread>
 #include <vector>
 
+#include <atomic>
+#include <mutex>
+
 #include "../../include/xvec_hip.h"
 
 struct xv_ark_reader {
@@ -33,12 +36,15 @@ struct xv_ark_reader {
   size_t pos = 0, end = 0;
   // a regular file opened by name is mapped: headers are parsed in place (no read() per record, no window to refill) and
   // the float payloads of a batch go from the page cache into the caller's (pinned) buffer by pread() from a few
-  // threads -- one copy, no page faults on the payload pages of the mapping
+  // threads -- one copy, no page faults on the payload pages of the mapping.  (Like every mmap reader: an ark that is
+  // TRUNCATED by another process while a job reads it ends that job with SIGBUS on the next header access, where the
+  // read() path reports "truncated"; payloads go through pread and report an error.  Arks are written once by the
+  // feature stage before extraction starts -- run_extract_embeddings.sh:43-47 -- so this is not a case the path meets.)
   void* map = nullptr;
   size_t map_len = 0;
   // mapped float payloads of the batch being assembled: copied at the end of xv_ark_next_batch, by a few threads
   struct Copy { int64_t off; float* dst; size_t bytes; };
-  bool copy_failed = false;
+  std::atomic<bool> copy_failed{false};   // set by any of the copy threads of run_copies
   std::vector<Copy> copies;
   int copy_threads = 1;
   bool eof = false;
@@ -128,7 +134,7 @@ void run_copies(xv_ark_reader* r) {
   for (const auto& x : c) total += x.bytes;
   const int nt = total >= ((size_t)2 << 20) ? r->copy_threads : 1;
   const int fd = r->fd;
-  bool* failed = &r->copy_failed;
+  std::atomic<bool>* failed = &r->copy_failed;
   auto work = [&c, fd, failed](size_t lo, size_t hi) {     // bytes [lo, hi) of the concatenation of all copies
     size_t at = 0;
     for (const auto& x : c) {
@@ -138,7 +144,7 @@ void run_copies(xv_ark_reader* r) {
       while (a < b) {
         const ssize_t got = pread(fd, reinterpret_cast<unsigned char*>(x.dst) + a, b - a, (off_t)(x.off + (int64_t)a));
         if (got < 0 && errno == EINTR) continue;
-        if (got <= 0) { *failed = true; return; }
+        if (got <= 0) { failed->store(true, std::memory_order_relaxed); return; }
         a += (size_t)got;
       }
       at += x.bytes;
@@ -506,7 +512,7 @@ int xv_ark_next_batch(xv_ark_reader* r, int64_t max_frames, int max_utts, int mi
     offsets[++n] = (int32_t)frames;
   }
   run_copies(r);
-  if (r->copy_failed) { r->copy_failed = false; return fail(r, "pread failed inside a matrix payload"); }
+  if (r->copy_failed.exchange(false)) { return fail(r, "pread failed inside a matrix payload"); }
   *n_utts = n;
   *dim = d < 0 ? 0 : d;
   return n;
@@ -560,6 +566,63 @@ int64_t xv_ark_format_vectors(const char* keys, int n, const float* data, int di
     k = e + 1;
   }
   return pos;
+}
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of `n` bytes, continuing from `crc` (0 to start): the checksum of the blocks
+// of a TF checkpoint-V2 index (LevelDB table format) and of its tensors (BundleEntryProto.crc32c); tf_checkpoint.py masks it.
+// SSE4.2 has the instruction; the table form is the fallback.
+namespace {
+uint32_t crc32c_table[8][256];
+bool crc32c_table_ready = false;
+void crc32c_init() {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0u);
+    crc32c_table[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; ++i)
+    for (int t = 1; t < 8; ++t) crc32c_table[t][i] = (crc32c_table[t - 1][i] >> 8) ^ crc32c_table[0][crc32c_table[t - 1][i] & 0xff];
+  crc32c_table_ready = true;
+}
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) uint32_t crc32c_hw(uint32_t c, const unsigned char* p, size_t n) {
+  uint64_t c64 = c;
+  while (n >= 8) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    c64 = __builtin_ia32_crc32di(c64, v);
+    p += 8;
+    n -= 8;
+  }
+  c = (uint32_t)c64;
+  while (n--) c = __builtin_ia32_crc32qi(c, *p++);
+  return c;
+}
+#endif
+}  // namespace
+
+uint32_t xv_crc32c(uint32_t crc, const void* data, int64_t n) {
+  if (!data || n <= 0) return crc;
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  uint32_t c = ~crc;
+#if defined(__x86_64__)
+  if (__builtin_cpu_supports("sse4.2")) return ~crc32c_hw(c, p, (size_t)n);
+#endif
+  static std::once_flag once;
+  std::call_once(once, crc32c_init);
+  size_t len = (size_t)n;
+  while (len >= 8) {                       // slicing-by-8
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = crc32c_table[7][lo & 0xff] ^ crc32c_table[6][(lo >> 8) & 0xff] ^ crc32c_table[5][(lo >> 16) & 0xff] ^ crc32c_table[4][lo >> 24] ^
+        crc32c_table[3][hi & 0xff] ^ crc32c_table[2][(hi >> 8) & 0xff] ^ crc32c_table[1][(hi >> 16) & 0xff] ^ crc32c_table[0][hi >> 24];
+    p += 8;
+    len -= 8;
+  }
+  while (len--) c = (c >> 8) ^ crc32c_table[0][(c ^ *p++) & 0xff];
+  return ~c;
 }
 
 }  // extern "C"

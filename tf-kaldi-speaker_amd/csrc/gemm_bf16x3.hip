@@ -432,7 +432,7 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
   const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr_t)As;
 
   auto dma_a = [&](int64_t koff, int buf, int g) {
-    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
+    const int c = lpc ^ (((lrow >> 1) & 3) << 1);          // slab swizzle (below): 2 * ((row >> 1) & 3), row = 8 g + lrow
     const char* src = Ag + (int64_t)(8 * g) * a_row_bytes + koff + c * 16;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * DA_BYTES + g * 1024);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" XV_TLAB_ANT ::"v"(src), "s"(dst) : "memory");
@@ -475,7 +475,12 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
     const int kbn = s + 2 < nsteps ? j2 * ncb + cb2 : 0;        // weights of step s + 2 (unconditional issue)
     const char* q = Wg + (int64_t)kbn * 4096;
     const char* ab = As + (cb & 1) * DA_BYTES + (c16 + j) * DROW;
-    const int aswz = ((c16 + j) >> 1) & 7;           // (16 ft + r) >> 1 == r >> 1 (mod 8): one swizzle for all eight tiles
+    // Slab swizzle: chunk c of slab row r lives at position c ^ 2 * ((r >> 1) & 3).  A ds_read_b128 is served in groups of 16
+    // lanes = 16 consecutive rows of which the outer eight read k chunk g4 and the inner eight g4 ^ 1 (lane groups of the
+    // instruction: MI355X_MICROARCH.md, LDS); with the tap shift j the window starts at any row, and only a swizzle that leaves
+    // bit 0 of the chunk alone keeps those two sets apart for every start (the round-2 swizzle (r >> 1) & 7 was conflict-free
+    // for j = 0 mod 4 only: tests/analysis/lds_bank_model.py, SQ_LDS_BANK_CONFLICT).  (16 ft + r) >> 1 == r >> 1 (mod 4).
+    const int aswz = (((c16 + j) >> 1) & 3) << 1;
     const int off_hi = (g4 ^ aswz) << 4, off_lo = ((4 + g4) ^ aswz) << 4;     // this lane's k chunk of the hi / lo half
     bf16x8 fh[8], fl[8];                 // activation fragments of frame tile ft, read two tiles ahead
     auto read_frag = [&](int ft) {
@@ -828,6 +833,7 @@ __global__ void bf16x3_tail_reduce_kernel(GemmArgs p, int mt0, int S) {
     if (p.Y && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;     // N % 4 == 0 (wide epilogue)
     if (p.Ysb && n < p.ldsb) {
       uint32_t h01, l01, h23, l23;
+      v *= p.sb_mul;
       split2(v[0], v[1], h01, l01, p.f16);
       split2(v[2], v[3], h23, l23, p.f16);
       if (p.f16) ovf_report(p.ovf, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));

@@ -10,7 +10,8 @@
 // Activation block of one (row, 32 channels), 128 bytes like the split-blocked format of xv_epilogue.h:
 //   chunks 0-3  32 x f16 hi (unchanged: the main fragment read is the one of the f16x3 kernel)
 //   chunk 4 / 5 bytes 0-15 of the 32 x 6-bit codes of q6(hi) / q6(lo)      chunk 6  their bytes 16-23 (hi | lo)
-//   chunk 7     byte 0 / 1: the E8M0 scales of q6(hi) / q6(lo)
+//   chunk 7     byte 0 / 1 of EVERY dword: the E8M0 scales of q6(hi) / q6(lo) (four copies, so that the reader can take the dword
+//               (row & 1) | ((row >> 4) & 1) << 1 and its 4-byte reads of 17 consecutive rows fall on 17 different banks)
 // One lane's operand of the scaled MFMA is one such block: lane l holds row / column l & 15 and K group l >> 4 = 32 consecutive K
 // elements, 32 x 6 bits little-endian, scale per lane (checked bit-exactly: tools/mfma_scale_probe.hip).  The K = 128 of a scaled
 // MFMA is "four taps of one channel block": group g reads slab row frame + 4q + g -- the rows the four main MFMAs of those taps read.
@@ -79,7 +80,8 @@ __global__ void f6_from_sb_kernel(const char* __restrict__ sb, char* __restrict_
   dst[4] = uint4{ch[0], ch[1], ch[2], ch[3]};
   dst[5] = uint4{cl[0], cl[1], cl[2], cl[3]};
   dst[6] = uint4{ch[4], ch[5], cl[4], cl[5]};
-  dst[7] = uint4{bh | (bl << 8), 0u, 0u, 0u};
+  const uint32_t sc2 = bh | (bl << 8);
+  dst[7] = uint4{sc2, sc2, sc2, sc2};        // four copies: the reader picks a dword by row (LDS bank spread)
 }
 
 #define XV6_GLD16(dst, ptr, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(dst) : "v"(ptr))
@@ -101,8 +103,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f16f6_kernel(GemmArgs p, int nMt,
   const int64_t a_row_bytes = p.ldsbx * 4;
   const char* Ag = reinterpret_cast<const char*>(p.Xsb) + (int64_t)(m0 + lrow) * a_row_bytes;
   const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr6_t)smem6;
+  // Slab swizzle (conflict-free for every tap shift and for the cross reads: tests/analysis/lds_bank_model.py).  With p = r >> 1:
+  //   chunks 0-3 (f16 hi)    at  c ^ f1(r),  f1 = 2 * (p & 3)                      -- a ds_read_b128 group is 16 consecutive rows of which
+  //                           the outer eight read k chunk g4 and the inner eight g4 ^ 1: bit 0 of the chunk must survive the swizzle;
+  //   chunks 4-7 (fp6, scale) at c ^ f2(r),  f2 = (p1 << 2) | (p2 << 1) | p0         -- all lanes read the SAME chunk of 16 consecutive
+  //                           rows: eight rows of one parity need eight positions.
+  // Bit 2 of f1 and f2 agree (p1), so the two halves of a row stay disjoint.  Row r = 8 g + lrow: p & 3 = lrow >> 1, p2 = g & 1.
+  const int swz1 = ((lrow >> 1) & 3) << 1;
+  const int swz2 = (((lrow >> 2) & 1) << 2) | ((lrow >> 1) & 1);                 // f2 without its bit 1 (= g & 1)
   auto dma_a = [&](int cb, int buf, int g) {                    // 8 rows x 128 B of channel block cb
-    const int c = lpc ^ ((4 * g + (lrow >> 1)) & 7);
+    // LDS position lpc of slab row r = 8 g + lrow holds chunk  lpc ^ f1(r)  or  lpc ^ f2(r)  (slab swizzle, below)
+    const int c = lpc ^ ((((lpc >> 2) ^ (lrow >> 2)) & 1) ? (swz2 ^ ((g & 1) << 1)) : swz1);
     const char* src = Ag + (int64_t)(8 * g) * a_row_bytes + (int64_t)cb * 128 + c * 16;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * F6_DA_BYTES + g * 1024);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
@@ -185,15 +196,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f16f6_kernel(GemmArgs p, int nMt,
   int xo[2][4], mo[2][4];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int rx = c16 + 4 * q + g4, sx = (rx >> 1) & 7;       // cross: K group g4 = tap 4q + g4
+    const int rx = c16 + 4 * q + g4, px = rx >> 1;             // cross: K group g4 = tap 4q + g4
+    const int sx = (((px >> 1) & 1) << 2) | (((px >> 2) & 1) << 1) | (px & 1);     // f2(rx); 16 rows further: the same
     xo[q][0] = rx * F6_DROW + ((4 ^ sx) << 4);
     xo[q][1] = rx * F6_DROW + ((5 ^ sx) << 4);
     xo[q][2] = rx * F6_DROW + ((6 ^ sx) << 4);
-    xo[q][3] = rx * F6_DROW + ((7 ^ sx) << 4);
+    // scale dword (rx & 1) | ((row >> 4) & 1) << 1 of chunk 7, row = 16 tile + rx: for odd tiles flip address bit 3
+    xo[q][3] = rx * F6_DROW + ((7 ^ sx) << 4) + (((rx & 1) | (((rx >> 4) & 1) << 1)) << 2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = c16 + 4 * q + j;
-      mo[q][j] = r * F6_DROW + ((g4 ^ ((r >> 1) & 7)) << 4);
+      mo[q][j] = r * F6_DROW + ((g4 ^ (((r >> 1) & 3) << 1)) << 4);
     }
   }
   // cross pass: the two block-scaled MFMAs of every tile.  Four MFMAs (64 cycles) per tile do not cover an LDS read, so the
@@ -201,15 +214,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16f6_kernel(GemmArgs p, int nMt,
   constexpr int XD = NTAPS <= 6 ? 4 : 3;
   auto cross_pass = [&](int cb, int q) __attribute__((always_inline)) {
     const char* slab = smem6 + (cb & 1) * F6_DA_BYTES;
-    v4i fh[XD], fl[XD];
-    v2i fth[XD], ftl[XD];
+    v4i fh[XD], fl[XD], ft[XD];              // codes 0-15 of q6(hi) / q6(lo); tails (hi | lo): one ds_read_b128 each, conflict-free
     int fs[XD];
     auto read_cross = [&](int g, int slot) __attribute__((always_inline)) {
       fh[slot] = *reinterpret_cast<const v4i*>(slab + xo[q][0] + g * 2048);
       fl[slot] = *reinterpret_cast<const v4i*>(slab + xo[q][1] + g * 2048);
-      fth[slot] = *reinterpret_cast<const v2i*>(slab + xo[q][2] + g * 2048);
-      ftl[slot] = *reinterpret_cast<const v2i*>(slab + xo[q][2] + g * 2048 + 8);
-      fs[slot] = *reinterpret_cast<const int*>(slab + xo[q][3] + g * 2048);
+      ft[slot] = *reinterpret_cast<const v4i*>(slab + xo[q][2] + g * 2048);
+      fs[slot] = *reinterpret_cast<const int*>(slab + (xo[q][3] ^ ((g & 1) << 3)) + g * 2048);
     };
 #pragma unroll
     for (int g = 0; g < XD - 1; ++g) read_cross(g, g);
@@ -217,8 +228,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16f6_kernel(GemmArgs p, int nMt,
     for (int g = 0; g < 8; ++g) {
       const int sl = g % XD;
       if (g + XD - 1 < 8) read_cross(g + XD - 1, (g + XD - 1) % XD);
-      const v8i a_hi6 = {fh[sl][0], fh[sl][1], fh[sl][2], fh[sl][3], fth[sl][0], fth[sl][1], 0, 0};
-      const v8i a_lo6 = {fl[sl][0], fl[sl][1], fl[sl][2], fl[sl][3], ftl[sl][0], ftl[sl][1], 0, 0};
+      const v8i a_hi6 = {fh[sl][0], fh[sl][1], fh[sl][2], fh[sl][3], ft[sl][0], ft[sl][1], 0, 0};
+      const v8i a_lo6 = {fl[sl][0], fl[sl][1], fl[sl][2], fl[sl][3], ft[sl][2], ft[sl][3], 0, 0};
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const v8i w_hi6 = {Xh[c][0], Xh[c][1], Xh[c][2], Xh[c][3], Xth[c][0], Xth[c][1], 0, 0};
@@ -323,11 +334,13 @@ hipError_t launch_f6_from_sb(const void* sb, void* out, int64_t rows, int nblk, 
 }
 
 // a.Xsb = activations in the block format above (row stride a.ldsbx channels), a.Wfr / a.Wx6 = main / cross weights
-// (xvec_api.hip, upload_layer), a.K = taps * a.cin, 4 <= taps <= 8, a.cin % 32 == 0
+// (xvec_api.hip, upload_layer), a.K = taps * a.cin, taps 5 or 7, a.cin % 32 == 0
 hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   const int taps = a.cin > 0 ? a.K / a.cin : 0;
-  if (taps < 4 || taps > 8 || (a.cin & 31) || a.ldsbx != a.cin || !a.Wx6 || !a.Wfr || a.a_pitch || a.pool_part || a.R || (a.N & 3))
+  // Only the widths the reference's graphs contain are instantiated (tdnn: 5, 5, 7; extended tdnn: 5, 5, 7 and a 9-tap layer that
+  // stays on the three-unit kernel): an 8-tap instantiation sits at 256 VGPRs with no headroom for its hand-counted waits.
+  if ((taps != 5 && taps != 7) || (a.cin & 31) || a.ldsbx != a.cin || !a.Wx6 || !a.Wfr || a.a_pitch || a.pool_part || a.R || (a.N & 3))
     return hipErrorInvalidValue;
   static std::mutex mu;
   static bool attr_set[64] = {};
@@ -337,9 +350,7 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
   {
     std::lock_guard<std::mutex> lock(mu);
     if (!attr_set[dev & 63]) {
-      const void* ks[] = {reinterpret_cast<const void*>(gemm_f16f6_kernel<4>), reinterpret_cast<const void*>(gemm_f16f6_kernel<5>),
-                          reinterpret_cast<const void*>(gemm_f16f6_kernel<6>), reinterpret_cast<const void*>(gemm_f16f6_kernel<7>),
-                          reinterpret_cast<const void*>(gemm_f16f6_kernel<8>)};
+      const void* ks[] = {reinterpret_cast<const void*>(gemm_f16f6_kernel<5>), reinterpret_cast<const void*>(gemm_f16f6_kernel<7>)};
       for (const void* k : ks) {
         const hipError_t r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (r != hipSuccess) return r;
@@ -349,13 +360,8 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
   }
   const int nMt = (a.M + F6_BM - 1) / F6_BM, nNt = a.Npad / F6_BN;
   const dim3 grid(nMt * nNt), block(256);
-  switch (taps) {
-    case 4: hipLaunchKernelGGL(gemm_f16f6_kernel<4>, grid, block, smem, s, a, nMt, nNt); break;
-    case 5: hipLaunchKernelGGL(gemm_f16f6_kernel<5>, grid, block, smem, s, a, nMt, nNt); break;
-    case 6: hipLaunchKernelGGL(gemm_f16f6_kernel<6>, grid, block, smem, s, a, nMt, nNt); break;
-    case 7: hipLaunchKernelGGL(gemm_f16f6_kernel<7>, grid, block, smem, s, a, nMt, nNt); break;
-    default: hipLaunchKernelGGL(gemm_f16f6_kernel<8>, grid, block, smem, s, a, nMt, nNt); break;
-  }
+  if (taps == 5) hipLaunchKernelGGL(gemm_f16f6_kernel<5>, grid, block, smem, s, a, nMt, nNt);
+  else hipLaunchKernelGGL(gemm_f16f6_kernel<7>, grid, block, smem, s, a, nMt, nNt);
   return hipGetLastError();
 }
 

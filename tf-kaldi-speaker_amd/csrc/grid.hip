@@ -209,7 +209,7 @@ constexpr int kConv0MaxC = 256, kConv0MaxF = 126;
 __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ off0,
                                                           int B, int F, int S, int C, const float* __restrict__ wdir, int act,
                                                           const float* __restrict__ alpha, float* __restrict__ y,
-                                                          char* __restrict__ ysb, int ldsb, int f16, int* __restrict__ ovf) {
+                                                          char* __restrict__ ysb, int ldsb, int f16, int* __restrict__ ovf, float sb_mul) {
   __shared__ float xs[3][kConv0MaxF + 2];
   __shared__ float wsm[11 * kConv0MaxC];
   const int64_t r = blockIdx.x;                               // padded time row of the batch
@@ -255,8 +255,9 @@ __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restri
       float m = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        split2(v[2 * e], v[2 * e + 1], hi[e], lo[e], f16);
-        m = fmaxf(m, fmaxf(fabsf(v[2 * e]), fabsf(v[2 * e + 1])));
+        const float a0 = v[2 * e] * sb_mul, a1 = v[2 * e + 1] * sb_mul;      // the split copy is kept at the layer's power-of-two scale
+        split2(a0, a1, hi[e], lo[e], f16);
+        m = fmaxf(m, fmaxf(fabsf(a0), fabsf(a1)));
       }
       if (f16) ovf_report(ovf, m);
       char* blk = ysb + p * (int64_t)ldsb * 4 + (c0 >> 5) * 128 + (c0 & 31) * 2;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void conv0_direct_kernel(const float* __restri
 // position is written as zero, so the whole output grid is defined without a memset.  Reads fp32, writes fp32 and / or SB.
 __global__ void grid_maxpool3x3_kernel(const float* __restrict__ x, const int32_t* __restrict__ off0, int B, int F, int S,
                                        int C, int64_t P, float* __restrict__ y, char* __restrict__ ysb, int ldsb, int f16,
-                                       int* __restrict__ ovf) {
+                                       int* __restrict__ ovf, float sb_mul) {
   const int quads = C >> 2;
   const int64_t total = P * quads;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -298,6 +299,7 @@ __global__ void grid_maxpool3x3_kernel(const float* __restrict__ x, const int32_
     if (y) *reinterpret_cast<f32x4*>(y + p * C + c) = v;
     if (ysb) {
       uint32_t h01, l01, h23, l23;
+      v *= sb_mul;
       split2(v[0], v[1], h01, l01, f16);
       split2(v[2], v[3], h23, l23, f16);
       if (f16) ovf_report(ovf, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
@@ -368,12 +370,12 @@ hipError_t launch_grid_zero_border(const int32_t* off0, int B, int64_t frames, i
 
 hipError_t launch_conv0_direct(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int S, int C, int64_t P,
                                const float* wdir, int act, const float* alpha, float* y, void* ysb, int ldsb, int f16, int* ovf,
-                               hipStream_t s) {
+                               float sb_mul, hipStream_t s) {
   const int64_t rows = S > 0 ? P / S : 0;                     // padded time rows of the batch
   if (rows <= 0) return hipSuccess;
   if (C > kConv0MaxC || F > kConv0MaxF || (C & 7) || rows * S != P) return hipErrorInvalidValue;
   hipLaunchKernelGGL(conv0_direct_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, ldx, off0, B, F, S, C, wdir, act, alpha, y,
-                     static_cast<char*>(ysb), ldsb, f16, ovf);
+                     static_cast<char*>(ysb), ldsb, f16, ovf, sb_mul);
   return hipGetLastError();
 }
 
@@ -406,11 +408,11 @@ hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0,
 }
 
 hipError_t launch_grid_maxpool3x3(const float* x, const int32_t* off0, int B, int F, int S, int C, int64_t P, float* y,
-                                  void* ysb, int ldsb, int f16, int* ovf, hipStream_t s) {
+                                  void* ysb, int ldsb, int f16, int* ovf, float sb_mul, hipStream_t s) {
   if (P <= 0) return hipSuccess;
   if (C & 3) return hipErrorInvalidValue;
   hipLaunchKernelGGL(grid_maxpool3x3_kernel, dim3(launch_blocks(P * (C >> 2))), dim3(256), 0, s, x, off0, B, F, S, C, P, y,
-                     static_cast<char*>(ysb), ldsb, f16, ovf);
+                     static_cast<char*>(ysb), ldsb, f16, ovf, sb_mul);
   return hipGetLastError();
 }
 

@@ -144,8 +144,9 @@ __device__ __forceinline__ void store_tile_scalar(const GemmArgs& p, const f32x1
     if (p.Y && nok) p.Y[(int64_t)orow * p.ldy + n] = v;
     if (p.Ysb && n < p.ldsb) {
       uint32_t hi, lo;
-      split2(v, 0.f, hi, lo, p.f16);
-      if (p.f16 && !(fabsf(v) <= kF16Max) && p.ovf) *p.ovf = 1;
+      const float vs = v * p.sb_mul;
+      split2(vs, 0.f, hi, lo, p.f16);
+      if (p.f16 && !(fabsf(vs) <= kF16Max) && p.ovf) *p.ovf = 1;
       uint16_t* blk = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128);
       blk[n & 31] = (uint16_t)hi;
       blk[32 + (n & 31)] = (uint16_t)lo;
@@ -172,8 +173,9 @@ __device__ __forceinline__ void store_tile16_scalar(const GemmArgs& p, const f32
     if (p.Y && nok) p.Y[(int64_t)orow * p.ldy + n] = v;
     if (p.Ysb && n < p.ldsb) {
       uint32_t hi, lo;
-      split2(v, 0.f, hi, lo, p.f16);
-      if (p.f16 && !(fabsf(v) <= kF16Max) && p.ovf) *p.ovf = 1;
+      const float vs = v * p.sb_mul;
+      split2(vs, 0.f, hi, lo, p.f16);
+      if (p.f16 && !(fabsf(vs) <= kF16Max) && p.ovf) *p.ovf = 1;
       uint16_t* blk = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128);
       blk[n & 31] = (uint16_t)hi;
       blk[32 + (n & 31)] = (uint16_t)lo;
@@ -287,6 +289,7 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
         }
         if (p.Ysb && n < p.ldsb) {
           uint32_t h01, l01, h23, l23;
+          v *= p.sb_mul;
           split2(v[0], v[1], h01, l01, p.f16);
           split2(v[2], v[3], h23, l23, p.f16);
           if (p.f16) ovf_report(p.ovf, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
@@ -311,7 +314,7 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
           params(nbase + ni * 32 + 8 * q + 4 * h, sc, sh, al);     // padding channels: scale = shift = 0 -> 0
 #pragma unroll
           for (int ml = 0; ml < MIP; ++ml) {
-            const f32x4 v = value4(acc[ni][ps * MIP + ml], q, sc, sh, al);
+            const f32x4 v = value4(acc[ni][ps * MIP + ml], q, sc, sh, al) * p.sb_mul;
             uint32_t h01, l01, h23, l23;
             split2(v[0], v[1], h01, l01, p.f16);
             split2(v[2], v[3], h23, l23, p.f16);
@@ -418,7 +421,10 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
 // LDS-staged epilogue of a 128-frame x 32-channel wave tile acc[ft][ct] (8 x 2 accumulator tiles of 16 frames x 16
 // channels, v_mfma_f32_16x16x32: lane & 15 -> frame, registers -> channels 4 * (lane >> 4) .. + 3; the "one wave per
 // 32-channel block" layout of the split kernels).  A row of the wave tile is exactly one SB block
-// (128 bytes) or 32 floats, so the scratch rows are 128 bytes (8 chunks, XOR-swizzled by frame & 7) and the
+// (128 bytes) or 32 floats, so the scratch rows are 128 bytes (8 chunks, XOR-swizzled by (frame >> 1) & 7: two rows fill the
+// 64 banks, so rows r and r + 1 may share a swizzle, and then all four access patterns below -- 16 consecutive rows per
+// ds_write_b64 group, 8 per ds_write_b128 group, 2 rows x 8 chunks per read-back group, one row per lane in xv_f6.h -- are
+// conflict-free; with frame & 7 the b64 writes and the row-per-lane phase were 2-way: tests/analysis/lds_bank_model.py) and the
 // read-back hands 8 lanes one whole 128-byte line.  ROWS frames per pass (ROWS * 128 bytes of scratch per wave);
 // the fused statistics pooling needs ROWS == 64 (its partial slots are per 64-frame tile).
 template <int ACT, int ROWS, bool F16>
@@ -432,6 +438,11 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   uint32_t bad = 0;                                     // F16 range guard: exponent-overflow bits of the converted hi halves
 
+  // GemmArgs::sb_mul (the power of two the split-blocked copy is kept at): when that copy is the only output it is folded into
+  // scale / shift here (every activation but tanh is positively homogeneous, and tanh layers have sb_mul == 1); otherwise the
+  // values are multiplied right before their split (uniform branch)
+  const bool fold = p.Ysb && !p.Y && !p.R && !p.pool_part && !p.raw;
+  const float sbm = fold ? 1.f : p.sb_mul;
   f32x4 sc[2], sh[2];                                   // this lane's channels 16 ct + 4 g4 .. +3, ct = 0, 1
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
@@ -443,6 +454,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       const bool ok = n4 < p.N;
       sc[ct] = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
       sh[ct] = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
+      if (fold) { sc[ct] *= p.sb_mul; sh[ct] *= p.sb_mul; }
     }
   }
   // Row map entries of every row this lane will store (8 per pass), loaded BEFORE the first store: vmcnt counts loads and
@@ -481,7 +493,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const int row = fl * 16 + c16;
-        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ (row & 7)) << 4)) = value4(acc[ps * FPP + fl][ct], ct, pre_act);
+        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ ((row >> 1) & 7)) << 4)) = value4(acc[ps * FPP + fl][ct], ct, pre_act);
       }
   };
   const int n = nbase + rchunk * 4;                      // read-back channels of this lane (fp32 forms)
@@ -497,7 +509,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       for (int it = 0; it < ROWS / 8; ++it) {
         const int row = it * 8 + rrow;
         const int m = mbase + ps * ROWS + row;
-        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ ((row >> 1) & 7)) << 4));
         bool zero;
         const int orow = out_row_pre(ps, it, zero);
         if (orow < 0) continue;
@@ -515,6 +527,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
         }
         if (p.Ysb && n < p.ldsb) {
           uint32_t h01, l01, h23, l23;
+          v *= p.sb_mul;
           split2t<F16>(v[0], v[1], h01, l01);
           split2t<F16>(v[2], v[3], h23, l23);
           if constexpr (F16) { ovf_bits(bad, h01); ovf_bits(bad, h23); }
@@ -536,7 +549,8 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       for (int fl = 0; fl < FPP; ++fl)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-          const f32x4 v = value4(acc[ps * FPP + fl][ct], ct, false);   // padding channels: scale = shift = 0 -> 0
+          f32x4 v = value4(acc[ps * FPP + fl][ct], ct, false);   // padding channels: scale = shift = 0 -> 0
+          if (sbm != 1.f) v *= sbm;
           uint32_t h01, l01, h23, l23;
           split2t<F16>(v[0], v[1], h01, l01);
           split2t<F16>(v[2], v[3], h23, l23);
@@ -546,8 +560,8 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
             if (mbase + ps * ROWS + row < p.M) { ovf_bits(bad, h01); ovf_bits(bad, h23); }
           }
           char* rp = scratch + row * 128 + 8 * (g4 & 1);
-          *reinterpret_cast<uint2*>(rp + (((2 * ct + (g4 >> 1)) ^ (row & 7)) << 4)) = make_uint2(h01, h23);
-          *reinterpret_cast<uint2*>(rp + (((4 + 2 * ct + (g4 >> 1)) ^ (row & 7)) << 4)) = make_uint2(l01, l23);
+          *reinterpret_cast<uint2*>(rp + (((2 * ct + (g4 >> 1)) ^ ((row >> 1) & 7)) << 4)) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(rp + (((4 + 2 * ct + (g4 >> 1)) ^ ((row >> 1) & 7)) << 4)) = make_uint2(l01, l23);
           if constexpr (F16) __builtin_amdgcn_sched_barrier(0);   // one tile at a time: the fp16 conversions of eight
                                                                   // interleaved tiles do not fit the register budget
         }
@@ -557,7 +571,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       for (int it = 0; it < ROWS / 8; ++it) {
         const int row = it * 8 + rrow;
         const int m = mbase + ps * ROWS + row;
-        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ ((row >> 1) & 7)) << 4));
         bool zero;
         const int orow = out_row_pre(ps, it, zero);
         if (zero) v = z;
@@ -582,7 +596,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
         for (int it = 0; it < ROWS / 8; ++it) {
           const int row = it * 8 + rrow;
           const int m = mbase + ps * ROWS + row;
-          f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
+          f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ ((row >> 1) & 7)) << 4));
           bool zero;
           const int orow = out_row_pre(ps, it, zero);
           if (zero) v = z;
@@ -598,7 +612,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
         const int my_utt = (mb + lane < p.M) ? p.pool_row2utt[mb + lane] : -1;
         const int tile64 = mb >> 6;
         auto row4 = [&](int t) -> f32x4 {
-          return *reinterpret_cast<const f32x4*>(scratch + t * 128 + ((rchunk ^ (t & 7)) << 4));
+          return *reinterpret_cast<const f32x4*>(scratch + t * 128 + ((rchunk ^ ((t >> 1) & 7)) << 4));
         };
         auto groups_sum = [&](f32x4 v) -> f32x4 {
 #pragma unroll
@@ -740,14 +754,14 @@ __device__ __forceinline__ void store_wave_tile_n32_att_impl(const GemmArgs& p, 
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const int row = fl * 16 + c16;
-        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ (row & 7)) << 4)) = value4(acc[ps * 4 + fl][ct], ct);
+        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ ((row >> 1) & 7)) << 4)) = value4(acc[ps * 4 + fl][ct], ct);
       }
     wave_lds_sync();
     const int mb = mbase + ps * 64;
     const int my_utt = (mb + lane < p.M) ? p.pool_row2utt[mb + lane] : -1;
     const int tile64 = mb >> 6;
     auto row4 = [&](int t) -> f32x4 {
-      return *reinterpret_cast<const f32x4*>(scratch + t * 128 + ((rchunk ^ (t & 7)) << 4));
+      return *reinterpret_cast<const f32x4*>(scratch + t * 128 + ((rchunk ^ ((t >> 1) & 7)) << 4));
     };
     auto groups_sum = [&](f32x4 v) -> f32x4 {
 #pragma unroll

@@ -51,8 +51,8 @@ __device__ __forceinline__ void store_wave_tile_n32_f6(const GemmArgs& p, const 
   for (int ct = 0; ct < 2; ++ct) {
     const int n4 = nbase + 16 * ct + 4 * g4;
     const bool ok = n4 < p.N;
-    sc[ct] = ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z;
-    sh[ct] = ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z;
+    sc[ct] = (ok ? *reinterpret_cast<const f32x4*>(p.scale + n4) : z) * p.sb_mul;      // block-format output only: the layer's power-of-two
+    sh[ct] = (ok ? *reinterpret_cast<const f32x4*>(p.shift + n4) : z) * p.sb_mul;      // activation scale is folded in (GemmArgs::sb_mul)
   }
   const bool blk_ok = nbase < p.ldsb;
 #pragma unroll
@@ -74,12 +74,12 @@ __device__ __forceinline__ void store_wave_tile_n32_f6(const GemmArgs& p, const 
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = apply_act(fmaf(t[i], sc[ct][i], sh[ct][i]), p.act, al[i]);
         const int row = fl * 16 + c16;
-        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ (row & 7)) << 4)) = v;
+        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ ((row >> 1) & 7)) << 4)) = v;
       }
     wave_lds_sync();
     {   // one row per lane
       char* rp = scratch + lane * 128;
-      const int sw = lane & 7;
+      const int sw = (lane >> 1) & 7;
       float x[32];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -120,13 +120,13 @@ __device__ __forceinline__ void store_wave_tile_n32_f6(const GemmArgs& p, const 
       *reinterpret_cast<uint4*>(rp + ((4 ^ sw) << 4)) = uint4{ch[0], ch[1], ch[2], ch[3]};
       *reinterpret_cast<uint4*>(rp + ((5 ^ sw) << 4)) = uint4{cl[0], cl[1], cl[2], cl[3]};
       *reinterpret_cast<uint4*>(rp + ((6 ^ sw) << 4)) = uint4{ch[4], ch[5], cl[4], cl[5]};
-      *reinterpret_cast<uint4*>(rp + ((7 ^ sw) << 4)) = uint4{bh | (bl << 8), 0u, 0u, 0u};
+      { const uint32_t sb2 = bh | (bl << 8); *reinterpret_cast<uint4*>(rp + ((7 ^ sw) << 4)) = uint4{sb2, sb2, sb2, sb2}; }   // four copies: the reader picks a dword by row (bank spread)
     }
     wave_lds_sync();
 #pragma unroll 4
     for (int it = 0; it < ROWS / 8; ++it) {
       const int row = it * 8 + rrow;
-      f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ (row & 7)) << 4));
+      f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ ((row >> 1) & 7)) << 4));
       int r = rmap[it];
       const bool zero = r < -1;
       r = zero ? -r - 2 : r;

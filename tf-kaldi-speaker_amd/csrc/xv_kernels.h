@@ -47,6 +47,9 @@ struct GemmArgs {
   int slab3 = 1;               // one-tap layers: three slab buffers / slabs two steps ahead (gemm_bf16x3_w1p3_kernel); 0 = the
                                // two-buffer kernel (same arithmetic, bit-identical results; xv_set_option "slab3")
   int* ovf = nullptr;          // f16 only: set to 1 when a value beyond the fp16 range was converted (checked by the host)
+  float sb_mul = 1.f;          // fp16 split formats: the split-blocked / fp6-block output holds y * sb_mul, a per-layer power of two that
+                               // keeps the activations' low halves normal (|y * sb_mul| ~ 2^4 rms; the reader's per-channel scale
+                               // carries 1 / sb_mul exactly: xvec_api.hip, act_exponent).  The fp32 output Y is never scaled.
   int f16 = 0;                 // split format of both operands: 0 = bf16 hi/lo (bf16x3), 1 = fp16 hi/lo (f16x3: same layout and
                                // MFMA rate, 11 + 11 significand bits instead of 8 + 8; values beyond +-65504 overflow)
   long long* trace = nullptr;  // debug: per-workgroup phase timestamps (XVEC_TRACE_K), 4 per workgroup
@@ -179,9 +182,9 @@ hipError_t launch_im2col2d_f32(const float* x, int64_t ldx, const int32_t* off0,
 // shift + activation, fp32 and / or split-blocked grid output (pitch S, border positions zero).  wdir = [9][C] kernel, scale[C], shift[C].
 hipError_t launch_conv0_direct(const float* x, int64_t ldx, const int32_t* off0, int B, int F, int S, int C, int64_t P,
                                const float* wdir, int act, const float* alpha, float* y, void* ysb, int ldsb, int f16, int* ovf,
-                               hipStream_t s);
+                               float sb_mul, hipStream_t s);
 hipError_t launch_grid_maxpool3x3(const float* x, const int32_t* off0, int B, int F, int S, int C, int64_t P, float* y,
-                                  void* ysb, int ldsb, int f16, int* ovf, hipStream_t s);
+                                  void* ysb, int ldsb, int f16, int* ovf, float sb_mul, hipStream_t s);
 // grid [P, C] -> dense [sum L_b * F, C] (drops the zero border; test / endpoint output only)
 hipError_t launch_grid_unpad_n(const float* grid, const int32_t* off0, int B, int F, int S, int C, int64_t frames, float* out,
                                hipStream_t s);

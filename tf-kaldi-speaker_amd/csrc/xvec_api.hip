@@ -87,6 +87,7 @@ struct Layer {
   bool has_bias = true;
   int K() const { return mode == 1 ? 9 * cin : (mode == 3 ? Fin * cin : (mode == 4 ? 9 : w * cin)); }
   DevBuf vec;                 // [bias | bn_scale | bn_shift | alpha | ones] each cout floats
+  int in_exp = 0, out_exp = 0; // fp16 split formats: the split copy of the input / output holds value * 2^exp (act_exponent below)
   bool use_f6 = false;        // XV_PREC_F16F6: this multi-tap convolution runs on gemm_f16f6_kernel (input converted to its block format)
   DevBuf wf6m, wf6x;          // its weights: f16 main fragments [N/32][cin/32][8 taps][2][64 lanes][16 B]; fp6 cross operands (gemm_f16f6.hip)
   DevBuf wdir;                // conv0 (mode 4): fp32 [9][cout] kernel, then bn_scale[cout], bn_shift[cout] (direct kernel, csrc/grid.hip)
@@ -118,6 +119,7 @@ struct Value {
   int ctx = 0;        // temporal context consumed (frame-level values): rows = F[tlevel] - B*ctx
   int tlevel = 0;     // time resolution: utterance b has ceil(L_b / 2^tlevel) frames (resnet_time_stride; else 0)
   int cols = 0;
+  int sb_exp = 0;     // fp16 split formats: the split-blocked copy of this value holds value * 2^sb_exp
 };
 
 struct Op {
@@ -163,7 +165,8 @@ struct xv_handle {
   std::vector<Node> nodes;
   // attention extras
   DevBuf query;                 // [H, dk_h]
-  DevBuf ovf_flag;              // f16x3: one int, set by any kernel that converted a value beyond the fp16 range
+  DevBuf ovf_flag;              // fp16 split formats, 4 ints: [0] set by any kernel that converted a value beyond the fp16 range;
+                                // [1] bits of the largest feature magnitude staged since the last reset (underflow guard)
   DevBuf query_eff;             // [H, Npad of the last key layer]: the query of head h over the padded key width, zero
                                 // outside the head's slice (fused score epilogue)
   int key_npad = 0;
@@ -680,6 +683,24 @@ void host_quant32(const float* v, unsigned char* codes24, unsigned char* scale_b
   *scale_byte = (unsigned char)byte;
 }
 
+// fp16 split formats (XV_PREC_F16X3 / F16F6): power of two the split copy of a layer's output is kept at.  hi + lo carries 22
+// significand bits only while the low half is a normal fp16 number (|x| >= 2^-3); below that it goes subnormal, and a layer whose
+// activations sit around 1e-3 would lose precision silently (there is a flag for the other end of the range, none for this one).
+// Behind a batch normalisation the pre-activation output of channel c is ~ N(beta_c, gamma_c^2) -- that is what the normalisation
+// is for -- so the layer's rms is known from the weights: the split copy holds y * 2^e with rms * 2^e ~ 2^4 (values below 2^-3 are
+// then < 1 % of the rms, four orders of magnitude of headroom to 65504 remain), and the reader's per-channel scale takes 2^-e
+// (exact).  Layers without a normalisation, and tanh (not homogeneous, bounded anyway), keep e = 0.
+int act_exponent(const xv_handle* h, const Layer& L) {
+  if (!L.has_bn || L.act == ACT_TANH) return 0;
+  const auto& g = T(h, L.bn_scope + "/gamma").data;
+  const auto& b = T(h, L.bn_scope + "/beta").data;
+  double s = 0.0;
+  for (size_t i = 0; i < g.size(); ++i) s += (double)g[i] * g[i] + (double)b[i] * b[i];
+  const double rms = std::sqrt(s / std::max<size_t>(g.size(), 1));
+  if (!(rms > 0.0) || !std::isfinite(rms)) return 0;
+  return (int)std::min(20.0, std::max(-20.0, std::floor(4.5 - std::log2(rms))));
+}
+
 int upload_layer(xv_handle* h, Layer& L) {
   const int K = L.K(), N = L.cout;
   // row of the packed weight matrix that holds kernel row k: identity, or tap * cin_pad + channel for a first layer
@@ -756,8 +777,8 @@ int upload_layer(xv_handle* h, Layer& L) {
           sb[blk + 32 + (kr & 31)] = f32_to_bf16_rn(wv - bf16_to_f32(a));
         }
       }
-    if (wscale != 1.f) {                             // fold 1/s into [bn_scale | ones]; bias / shift are not products
-      const float inv = 1.f / wscale;
+    if (wscale != 1.f || L.in_exp != 0) {             // fold 1/s into [bn_scale | ones]; bias / shift are not products
+      const float inv = std::ldexp(1.f / wscale, -L.in_exp);          // (and the power of two the input's split copy is kept at)
       for (int n = 0; n < N; ++n) { vec[(size_t)N + n] *= inv; vec[(size_t)4 * N + n] *= inv; }
       XV_HIP(h, hipMemcpy(L.vec.p, vec.data(), vec.size() * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -924,12 +945,24 @@ int xv_finalize(xv_handle* h) {
       L.im2col = bf && op.in0 == 0;
       L.cin_pad = (L.im2col && L.w <= 9) ? (int)align_up(L.cin, 32) : 0;
       L.use_split = L.im2col || (bf && vin.frame_level && (L.w == 1 || (L.cin % 32 == 0 && L.w <= 9)));   // slab halo of the split kernel
-      // two-unit split: 4..8 taps over whole 32-channel blocks (the first layer, K = 5 x 30, stays on the f16 kernel and writes
+      // two-unit split: the 5- and 7-tap layers over whole 32-channel blocks (the first layer, K = 5 x 30, stays on the f16 kernel and writes
       // the block format of its reader: gemm_bf16x3_w14p2_kernel<1, 3, true>)
-      L.use_f6 = h->desc.precision == XV_PREC_F16F6 && L.use_split && !L.im2col && L.w >= 4 && L.w <= 8 && L.cin % 32 == 0 &&
+      L.use_f6 = h->desc.precision == XV_PREC_F16F6 && L.use_split && !L.im2col && (L.w == 5 || L.w == 7) && L.cin % 32 == 0 &&
                  L.cout % 4 == 0;
     } else {      // grid convolutions: whole SB blocks per tap; conv0 goes through its own im2col
       L.use_split = bf && (L.mode == 4 || L.cin % 32 == 0);
+    }
+  }
+  if (h->desc.precision == XV_PREC_F16X3 || h->desc.precision == XV_PREC_F16F6) {
+    for (const Op& op : h->ops) {      // creation order is topological: a value's exponent is known before its readers
+      if (op.kind == OP_GEMM) {
+        Layer& L = h->layers[op.layer];
+        L.in_exp = (L.use_split && !L.im2col && L.mode != 4 && op.in0 > 0) ? h->values[op.in0].sb_exp : 0;
+        L.out_exp = act_exponent(h, L);
+        h->values[op.out].sb_exp = L.out_exp;
+      } else if (op.kind == OP_GRID_MAXPOOL) {
+        h->values[op.out].sb_exp = h->values[op.in0].sb_exp;
+      }
     }
   }
   for (auto& L : h->layers) {
@@ -966,8 +999,8 @@ int xv_finalize(xv_handle* h) {
       XV_HIP(h, hipMemcpy(h->post_vec.p, vec.data(), vec.size() * sizeof(float), hipMemcpyHostToDevice));
     }
   }
-  XV_HIP(h, h->ovf_flag.alloc(sizeof(int)));
-  XV_HIP(h, hipMemset(h->ovf_flag.p, 0, sizeof(int)));
+  XV_HIP(h, h->ovf_flag.alloc(4 * sizeof(int)));
+  XV_HIP(h, hipMemset(h->ovf_flag.p, 0, 4 * sizeof(int)));
   XV_HIP(h, hipDeviceSynchronize());
   for (auto& kv : h->tensors) { kv.second.data.clear(); kv.second.data.shrink_to_fit(); }
   h->finalized = true;
@@ -991,10 +1024,31 @@ int xv_check_overflow(xv_handle* h, int reset) {
   if (!h) return fail(nullptr, XV_ERR_INVALID, "xv_check_overflow: null handle");
   if (!h->finalized || !h->ovf_flag.p) return 0;
   DeviceGuard g(h->device);
-  int v = 0;
-  XV_HIP(h, hipMemcpy(&v, h->ovf_flag.p, sizeof(int), hipMemcpyDeviceToHost));
-  if (v && reset) XV_HIP(h, hipMemset(h->ovf_flag.p, 0, sizeof(int)));
-  return v ? 1 : 0;
+  int32_t v[2] = {0, 0};
+  XV_HIP(h, hipMemcpy(v, h->ovf_flag.p, sizeof(v), hipMemcpyDeviceToHost));
+  if ((v[0] || v[1]) && reset) XV_HIP(h, hipMemset(h->ovf_flag.p, 0, sizeof(v)));
+  return xv_flags_decode(v);
+}
+
+int xv_flags_decode(const int32_t* flags) {
+  if (!flags) return XV_ERR_INVALID;
+  if (flags[0]) return 1;
+  if (flags[1] > 0) {                    // bits of the largest |feature| staged (0: no feature staged, or all zero)
+    float mx;
+    memcpy(&mx, &flags[1], 4);
+    if (mx < 0.00390625f) return 2;      // 2^-8
+  }
+  return 0;
+}
+
+int xv_flags_async(xv_handle* h, int32_t* host_flags, void* stream) {
+  if (!h || !host_flags) return fail(h, XV_ERR_INVALID, "xv_flags_async: null argument");
+  if (!h->finalized || !h->ovf_flag.p) { host_flags[0] = host_flags[1] = 0; return XV_OK; }
+  DeviceGuard g(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  XV_HIP(h, hipMemcpyAsync(host_flags, h->ovf_flag.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  XV_HIP(h, hipMemsetAsync(h->ovf_flag.p, 0, 2 * sizeof(int32_t), s));
+  return XV_OK;
 }
 
 int xv_node_id(const xv_handle* h, const char* name) {
@@ -1569,6 +1623,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         a.f16 = f16;
         a.slab3 = h->opt_slab3;
         a.ovf = static_cast<int*>(h->ovf_flag.p);
+        a.sb_mul = std::ldexp(1.f, L.out_exp);
         const Value& vo = h->values[op.out];
         if (vo.grid_F > 0) {
           // the border of a grid output must be zero.  Covered outputs: the layer's own zero-writing rows do it, except
@@ -1641,7 +1696,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
             XV_HIP(h, launch_conv0_direct(feats, feat_ld, off, B, L.Fout, vo.grid_S, L.cout, st.M, static_cast<const float*>(L.wdir.p),
                                           L.act, L.d_alpha(), st.out_off >= 0 ? reinterpret_cast<float*>(ws + st.out_off) : nullptr,
                                           st.out_sb_off >= 0 ? ws + st.out_sb_off : nullptr, sb_ld(L.cout), f16,
-                                          static_cast<int*>(h->ovf_flag.p), s));
+                                          static_cast<int*>(h->ovf_flag.p), a.sb_mul, s));
             break;
           }
           if (L.use_split) {
@@ -1791,7 +1846,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
         float* y = st.out_off >= 0 ? reinterpret_cast<float*>(ws + st.out_off) : nullptr;
         XV_HIP(h, launch_grid_maxpool3x3(in_ptr(st.in0_off), off, B, vo.grid_F, vo.grid_S, vo.cols, st.rows_out, y,
                                          st.out_sb_off >= 0 ? ws + st.out_sb_off : nullptr, sb_ld(vo.cols), f16,
-                                         static_cast<int*>(h->ovf_flag.p), s));
+                                         static_cast<int*>(h->ovf_flag.p), std::ldexp(1.f, vo.sb_exp), s));
         if (st.unpad_to_out)
           XV_HIP(h, launch_grid_unpad_n(y, off_out, B, vo.grid_F, vo.grid_S, vo.cols, st.frames_out, out, s));
         break;
@@ -1916,7 +1971,7 @@ void xv_destroy(xv_handle* h) {
   if (!h) return;
   {
     DeviceGuard g(h->device);
-    for (auto& L : h->layers) { L.wt.release(); L.wsb.release(); L.wfr.release(); L.vec.release(); }
+    for (auto& L : h->layers) { L.wt.release(); L.wsb.release(); L.wfr.release(); L.vec.release(); L.wf6m.release(); L.wf6x.release(); L.wdir.release(); }
     h->query.release();
     h->ovf_flag.release();
     h->query_eff.release();

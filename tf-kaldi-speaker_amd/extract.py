@@ -208,15 +208,27 @@ def _vad_records(vad_rspecifier):
 
 
 def _vad_lookup(vad_rspecifier):
-    """Lock-step lookup in a VAD vector table that is in the same key order as the features (Kaldi's `scp,s,cs`
-    contract of select-voiced-frames): returns f(key) -> vector, skipping VAD entries without features."""
+    """Lock-step lookup in a VAD vector table that is in the same (sorted) key order as the features (Kaldi's `scp,s,cs`
+    contract of select-voiced-frames): returns f(key) -> vector, skipping VAD entries without features.  An utterance
+    without VAD decisions gives None -- select-voiced-frames warns and drops it, it does not end the job -- and the
+    caller counts it as skipped."""
     it = iter(_vad_records(vad_rspecifier))
+    held = []                               # one VAD record read ahead of the features (its key sorts behind the one asked for)
 
     def lookup(key):
-        for k, v in it:
+        while True:
+            if held:
+                k, v = held.pop()
+            else:
+                try:
+                    k, v = next(it)
+                except StopIteration:
+                    return None
             if k == key:
                 return v
-        raise KeyError("no VAD decisions for utterance %s (VAD ark must be in feature order)" % key)
+            if k > key:                     # sorted tables: the VAD table has no entry for `key`
+                held.append((k, v))
+                return None
     return lookup
 
 
@@ -281,6 +293,9 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
         if frontend:
             from .frontend import cmn_select_packed
             vads = [vad_of(k) for k in keys] if vad_of else None
+            if vads is not None and any(v is None for v in vads):
+                missing = [k for k, v in zip(keys, vads) if v is None]
+                log.warning("[WARNING] no VAD decisions for %d utterance(s) (first: %s): skipped" % (len(missing), missing[0]))
             with torch.cuda.device(dev_index):
                 raw = torch.from_numpy(feats).to("cuda:%d" % dev_index, non_blocking=True)
                 dev, offsets, kept = cmn_select_packed(raw, offsets, vads, cmn_window=cmn_window,

@@ -11,7 +11,8 @@ from . import _lib
 def cmn_select_packed(feats_dev, offsets, vads, cmn_window=300, center=True, min_window=100, dim=None, device_index=None,
                       min_frames=0):
     """feats_dev: CUDA float32 [frames, ld] (raw features of B utterances back to back); offsets: B+1 frame
-    offsets; vads: list of B per-frame VAD arrays (non-zero = keep) or None to keep every frame.
+    offsets; vads: list of B per-frame VAD arrays (non-zero = keep; None = utterance without decisions: dropped) or None to
+    keep every frame.
     Utterances left with fewer than min_frames frames are dropped (the reference's extract.py:65-67 sees the
     lengths after select-voiced-frames).
     Returns (out CUDA float32 [kept_frames, dim], new offsets int32 [B'+1], indices of the B' kept utterances)."""
@@ -25,6 +26,8 @@ def cmn_select_packed(feats_dev, offsets, vads, cmn_window=300, center=True, min
         n = int(offsets[b + 1] - offsets[b])
         if vads is None:
             idx = np.arange(offsets[b], offsets[b + 1], dtype=np.int32)
+        elif vads[b] is None:                # no VAD decisions for this utterance: dropped, as select-voiced-frames does
+            continue
         else:
             v = np.asarray(vads[b])
             if v.shape[0] != n:

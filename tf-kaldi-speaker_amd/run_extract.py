@@ -146,6 +146,19 @@ def make_shards(data_dir, out_dir, nj, use_vad=True, lengths=None):
     if len(lengths) != len(keys):
         raise ValueError("feats.scp has %d entries, %d lengths" % (len(keys), len(lengths)))
     vad = dict(read_table(os.path.join(data_dir, "vad.scp"))) if use_vad else None
+    if vad is not None:
+        # select-voiced-frames ark:- scp,s,cs:vad.scp (run_extract_embeddings.sh:47) warns about an utterance without VAD decisions
+        # and goes on: such utterances are dropped here (and counted), they do not end the run
+        missing = [k for k in keys if k not in vad]
+        if missing:
+            print("run_extract_embeddings: WARNING: %d of %d utterances have no entry in vad.scp and are skipped (first: %s)"
+                  % (len(missing), len(keys), missing[0]))
+            keep = [i for i, k in enumerate(keys) if k in vad]
+            if not keep:
+                raise ValueError("no utterance of feats.scp has an entry in vad.scp")
+            feats = [feats[i] for i in keep]
+            keys = [keys[i] for i in keep]
+            lengths = lengths[keep]
     shards = sharding.lpt_shards(lengths, nj)
     for j, idx in enumerate(shards):
         sdir = os.path.join(out_dir, "split%d" % nj, str(j + 1))
@@ -157,8 +170,6 @@ def make_shards(data_dir, out_dir, nj, use_vad=True, lengths=None):
             with open(os.path.join(sdir, "vad.scp"), "w") as f:
                 for i in idx:
                     k = keys[i]
-                    if k not in vad:
-                        raise KeyError("utterance %s has no entry in vad.scp" % k)
                     f.write("%s %s\n" % (k, vad[k]))
     return keys, lengths, shards
 

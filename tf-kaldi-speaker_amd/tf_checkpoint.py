@@ -11,8 +11,11 @@ without TensorFlow.
 STATUS: **parity unpinned** -- no real checkpoint ships with the reference (README.md:101-119 are
 remote links) and TensorFlow is not installed here, so the parser is written from the published
 format (tensor_bundle.proto, table_builder.cc / format.cc) and tested only against the writer below
-(round trip, tests/test_tf_checkpoint.py).  Block compression: none (what BundleWriter emits);
-snappy blocks raise.  CRCs are not verified.
+(round trip, tests/test_tf_checkpoint.py; one index assembled byte by byte in the test itself).  Block compression:
+none (what BundleWriter emits); snappy blocks raise.  Checksums ARE verified, as TensorFlow's BundleReader does: the masked
+CRC-32C behind every table block (LevelDB format.cc: crc32c(block | type byte), Mask = rotr15 + 0xa282ead8) and the masked
+CRC-32C of every tensor's bytes (BundleEntryProto.crc32c); a mismatch raises CheckpointFormatError("checksum").  Known-answer
+vectors of the checksum itself (RFC 3720 B.4) are in the tests.
 """
 import os
 import struct
@@ -31,6 +34,58 @@ _DT_CODE = {np.dtype("float32"): 1, np.dtype("float64"): 2, np.dtype("int32"): 3
 
 class CheckpointFormatError(Exception):
     pass
+
+
+# ------------------------------------------------------------------------------ CRC-32C
+_CRC_TABLE = None
+_native_crc = None
+
+
+def _crc32c_py(crc, data):
+    global _CRC_TABLE
+    if _CRC_TABLE is None:
+        tab = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ (0x82F63B78 if c & 1 else 0)
+            tab.append(c)
+        _CRC_TABLE = tab
+    c = crc ^ 0xFFFFFFFF
+    tab = _CRC_TABLE
+    for b in bytes(data):
+        c = (c >> 8) ^ tab[(c ^ b) & 0xFF]
+    return c ^ 0xFFFFFFFF
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli) of `data` (bytes-like), continuing from `crc`.  Uses the native routine of libxvec_hip.so
+    (xv_crc32c: the SSE4.2 instruction) when the library is built -- a released model has ~20 MB of tensors -- and a
+    table loop otherwise."""
+    global _native_crc
+    if _native_crc is None:
+        try:
+            import ctypes
+            from . import _lib
+            fn = _lib.load().xv_crc32c
+            _native_crc = lambda c, d: int(fn(c, ctypes.c_char_p(d) if isinstance(d, bytes) else
+                                              ctypes.cast((ctypes.c_char * len(d)).from_buffer_copy(d), ctypes.c_void_p), len(d)))
+        except Exception:
+            _native_crc = False
+    data = bytes(data) if not isinstance(data, bytes) else data
+    if _native_crc:
+        return _native_crc(crc, data)
+    return _crc32c_py(crc, data)
+
+
+def mask_crc(crc):
+    """LevelDB / TensorFlow crc32c::Mask: rotate right by 15 bits and add a constant (a CRC of data that contains CRCs)."""
+    return ((((crc >> 15) | (crc << 17)) & 0xFFFFFFFF) + 0xa282ead8) & 0xFFFFFFFF
+
+
+def unmask_crc(masked):
+    rot = (masked - 0xa282ead8) & 0xFFFFFFFF
+    return ((rot >> 17) | (rot << 15)) & 0xFFFFFFFF
 
 
 # ------------------------------------------------------------------------------ varint / proto helpers
@@ -103,7 +158,7 @@ def _parse_shape(buf):
 
 def _parse_entry(buf):
     """BundleEntryProto: dtype=1, shape=2, shard_id=3, offset=4, size=5, crc32c=6 (fixed32), slices=7."""
-    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0, "slices": 0}
+    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0, "slices": 0, "crc32c": None}
     for field, _, v in _proto_fields(buf):
         if field == 1:
             e["dtype"] = v
@@ -115,6 +170,8 @@ def _parse_entry(buf):
             e["offset"] = v
         elif field == 5:
             e["size"] = v
+        elif field == 6:
+            e["crc32c"] = struct.unpack("<I", bytes(v))[0]
         elif field == 7:
             e["slices"] += 1
     return e
@@ -135,6 +192,9 @@ def _read_block(data, off, size):
     ctype = data[off + size]
     if ctype != 0:
         raise CheckpointFormatError("compressed table block (type %d): only uncompressed bundles are supported" % ctype)
+    stored = struct.unpack("<I", data[off + size + 1:off + size + 5])[0]
+    if unmask_crc(stored) != crc32c(data[off:off + size + 1]):            # block contents + the type byte (format.cc, ReadBlock)
+        raise CheckpointFormatError("table block at offset %d: checksum mismatch (corrupt index file)" % off)
     block = data[off:off + size]
     if size < 4:
         raise CheckpointFormatError("block too small")
@@ -203,6 +263,8 @@ def read_bundle(prefix, name_filter=None):
             n = int(np.prod(e["shape"])) if e["shape"] else 1
             if len(raw) != e["size"] or n * dt.itemsize != e["size"]:
                 raise CheckpointFormatError("variable %s: size %d does not match shape %s" % (name, e["size"], e["shape"]))
+            if e["crc32c"] is not None and unmask_crc(e["crc32c"]) != crc32c(raw):       # tensor_bundle.cc, BundleReader::GetValue
+                raise CheckpointFormatError("variable %s: checksum mismatch (corrupt data shard %d)" % (name, sid))
             out[name] = np.frombuffer(raw, dtype=dt).reshape(e["shape"]).copy()
     finally:
         for fh in files.values():
@@ -215,15 +277,17 @@ def _enc_field(field, wt, payload):
     return _enc_varint((field << 3) | wt) + payload
 
 
-def _enc_entry(arr, offset):
+def _enc_entry(arr, offset, shard=0):
     shape = b"".join(_enc_field(2, 2, _enc_varint(len(d)) + d)
                      for d in (_enc_field(1, 0, _enc_varint(int(s))) for s in arr.shape))
     msg = _enc_field(1, 0, _enc_varint(_DT_CODE[arr.dtype]))
     msg += _enc_field(2, 2, _enc_varint(len(shape)) + shape)
+    if shard:
+        msg += _enc_field(3, 0, _enc_varint(shard))
     if offset:
         msg += _enc_field(4, 0, _enc_varint(offset))
     msg += _enc_field(5, 0, _enc_varint(arr.nbytes))
-    msg += _enc_field(6, 5, struct.pack("<I", 0))
+    msg += _enc_field(6, 5, struct.pack("<I", mask_crc(crc32c(arr.tobytes()))))
     return msg
 
 
@@ -246,32 +310,43 @@ def _build_block(items, restart_interval=16):
     return bytes(out)
 
 
-def write_bundle(prefix, tensors, block_entries=8):
-    """Write {name: ndarray} as a single-shard V2 bundle in the layout read_bundle expects (uncompressed
-    blocks, prefix-compressed keys, zero CRCs).  For tests and for converting an .npz back; NOT verified
-    against TensorFlow's own reader."""
+def _block_trailer(block):
+    """type byte (0 = uncompressed) + masked CRC-32C of block | type (table_builder.cc, WriteRawBlock)"""
+    return b"\x00" + struct.pack("<I", mask_crc(crc32c(block + b"\x00")))
+
+
+def write_bundle(prefix, tensors, block_entries=8, shards=1, restart_interval=16):
+    """Write {name: ndarray} as a V2 bundle of `shards` data files in the layout read_bundle expects (uncompressed
+    blocks, prefix-compressed keys with a restart point every `restart_interval` entries, block and tensor checksums).
+    For tests and for converting an .npz back; NOT verified against TensorFlow's own reader."""
     names = sorted(tensors)
-    offset, items = 0, [(b"", _enc_field(1, 0, _enc_varint(1)) + _enc_field(2, 0, _enc_varint(0)))]
-    with open(prefix + ".data-00000-of-00001", "wb") as f:
-        for n in names:
+    items = [(b"", _enc_field(1, 0, _enc_varint(shards)) + _enc_field(2, 0, _enc_varint(0)))]
+    files = [open("%s.data-%05d-of-%05d" % (prefix, i, shards), "wb") for i in range(shards)]
+    offsets = [0] * shards
+    try:
+        for i, n in enumerate(names):
             a = np.asarray(tensors[n])                 # (ascontiguousarray would promote 0-d to 1-d)
             if a.dtype not in _DT_CODE:
                 a = a.astype(np.float32)
-            items.append((n.encode("utf-8"), _enc_entry(a, offset)))
-            f.write(a.tobytes())
-            offset += a.nbytes
+            sid = i % shards
+            items.append((n.encode("utf-8"), _enc_entry(a, offsets[sid], sid)))
+            files[sid].write(a.tobytes())
+            offsets[sid] += a.nbytes
+    finally:
+        for fh in files:
+            fh.close()
     data, index_items = bytearray(), []
     for i in range(0, len(items), block_entries):
         chunk = items[i:i + block_entries]
-        block = _build_block(chunk)
+        block = _build_block(chunk, restart_interval)
         index_items.append((chunk[-1][0], _enc_varint(len(data)) + _enc_varint(len(block))))
-        data += block + b"\x00" + b"\x00\x00\x00\x00"
+        data += block + _block_trailer(block)
     meta = _build_block([])
     meta_handle = _enc_varint(len(data)) + _enc_varint(len(meta))
-    data += meta + b"\x00" + b"\x00\x00\x00\x00"
+    data += meta + _block_trailer(meta)
     index = _build_block(index_items, restart_interval=1)
     index_handle = _enc_varint(len(data)) + _enc_varint(len(index))
-    data += index + b"\x00" + b"\x00\x00\x00\x00"
+    data += index + _block_trailer(index)
     footer = meta_handle + index_handle
     footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", _TABLE_MAGIC)
     with open(prefix + ".index", "wb") as f:

@@ -26,6 +26,16 @@ _F16_RANGE = ("f16x3", "f16f6")       # precisions whose activations must stay w
 DEFAULT_PRECISION = "bf16x3"
 
 
+def default_precision(network_type):
+    """What Trainer, the command-line drivers and bench.py run when no precision is named.  The TDNN runs in f16f6: the fastest
+    precision, under the same GPU parity suite as the others (tests/test_gpu_parity.py: every endpoint, both poolings, ragged
+    batches, the rescaled-layer and feature-range tests), with both ends of the fp16 range guarded (values beyond +-65504 and
+    feature batches below 2^-8 raise FloatingPointError instead of producing wrong vectors).  The extended TDNN (its 9-tap layer
+    stays on the three-unit kernel, where fp16 halves run ~3 % slower than bf16) and the ResNet keep bf16x3, which has
+    the full fp32 exponent range and no such refusals."""
+    return "f16f6" if network_type == "tdnn" else DEFAULT_PRECISION
+
+
 def _relu_type(params):
     t = params.dict.get("network_relu_type")
     return {"prelu": _lib.XV_ACT_PRELU, "lrelu": _lib.XV_ACT_LRELU}.get(t, _lib.XV_ACT_RELU)
@@ -63,7 +73,7 @@ class Trainer(object):
         self.is_loaded = False
         self.first_feature_split_alert = True
         self.embeddings = None            # name of the endpoint predict() returns
-        self._precision = precision or os.environ.get("XVEC_PRECISION", DEFAULT_PRECISION)
+        self._precision = precision or os.environ.get("XVEC_PRECISION") or default_precision(params.network_type)
         if self._precision not in _PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
         if device is None:
@@ -348,18 +358,38 @@ class Trainer(object):
         return {f[0]: getattr(info, f[0]) for f in info._fields_}
 
     def check_overflow(self):
-        """f16x3 only: True if a feature or activation went beyond the fp16 range (+-65504) in a forward since the
-        last check (xv_check_overflow; synchronous -- call after the results have been fetched)."""
+        """fp16 split precisions only: 1 if a feature or activation went beyond the fp16 range (+-65504) in a forward since
+        the last check, 2 if every feature staged since then was below 2^-8 in magnitude (the low halves of the split are
+        subnormal there), else 0 (xv_check_overflow; synchronous -- call after the results have been fetched)."""
         if self._precision not in _F16_RANGE or self._h is None:
-            return False
-        return _lib.check(self._lib.xv_check_overflow(self._h, 1), self._h) == 1
+            return 0
+        return _lib.check(self._lib.xv_check_overflow(self._h, 1), self._h)
+
+    def flags_async(self, host_flags):
+        """Stream-ordered form of check_overflow (xv_flags_async): `host_flags` is a pinned int32 tensor of 2 elements that
+        receives the flag words behind everything enqueued on the current stream; decode with raise_on_flags() once an
+        event recorded after this call has completed."""
+        if self._precision not in _F16_RANGE or self._h is None:
+            host_flags.zero_()
+            return
+        stream = self._torch.cuda.current_stream(self._device_index).cuda_stream
+        _lib.check(self._lib.xv_flags_async(self._h, C.c_void_p(host_flags.data_ptr()), C.c_void_p(stream)), self._h)
+
+    def raise_on_flags(self, code, emb=None):
+        if code == 1 or (emb is not None and self._precision in _F16_RANGE and not np.isfinite(emb).all()):
+            raise FloatingPointError("the %s path converted a value beyond the fp16 range (+-65504): an input feature or an "
+                                     "activation is too large; run with precision 'bf16x3' (full fp32 range) or 'f32'" % self._precision)
+        if code == 2:
+            raise FloatingPointError("every input feature of the batch is below 2^-8 in magnitude: the %s path would lose precision "
+                                     "silently (subnormal low halves); rescale the features or run with precision 'bf16x3'" % self._precision)
+
+    def decode_flags(self, host_flags):
+        return int(self._lib.xv_flags_decode(C.c_void_p(host_flags.data_ptr()))) if self._lib is not None else 0
 
     def _checked(self, emb):
-        """Host copies of f16x3 results are range-checked, so that an overflow fails loudly instead of writing wrong
+        """Host copies of fp16-split results are range-checked, so that an overflow fails loudly instead of writing wrong
         vectors into an ark (ReLU turns the NaNs an overflow produces into zeros: the output itself can look finite)."""
-        if self.check_overflow() or (self._precision in _F16_RANGE and not np.isfinite(emb).all()):
-            raise FloatingPointError("the f16x3 path converted a value beyond the fp16 range (+-65504): an input feature or an "
-                                     "activation is too large; run with precision 'bf16x3' (full fp32 range) or 'f32'")
+        self.raise_on_flags(self.check_overflow(), emb)
         return emb
 
     def _lazy_load(self):
