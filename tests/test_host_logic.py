@@ -108,7 +108,7 @@ def test_c_abi_library_exports_every_declared_symbol(repo_root):
     import __graft_entry__ as g
     g.build()
     hdr = open(os.path.join(repo_root, "include", "xvec_hip.h")).read()
-    declared = set(re.findall(r"\b(xv_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(xv_[a-z0-9_]+)\s*\(", hdr))
     from tf_kaldi_speaker_amd import _lib
     assert declared == set(_lib.EXPORTS)
     lib = ctypes.CDLL(_lib.LIB_PATH)
