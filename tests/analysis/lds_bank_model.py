@@ -75,12 +75,34 @@ def cross_reads_new():
     return tot
 
 
-def epilogue_rowlane(f):
-    tot = 0
-    for q in range(8):
-        addrs = [lane * 128 + ((q ^ f(lane)) << 4) for lane in range(64)]
-        tot += 2 * extra_cycles(addrs, 16)        # read + write back
-    return tot
+W64 = [list(range(16 * i, 16 * i + 16)) for i in range(4)]      # ds_write_b64: 4 x 16 contiguous lanes, 32 banks
+W128 = [list(range(8 * i, 8 * i + 8)) for i in range(8)]        # ds_write_b128: 8 x 8 contiguous lanes, 32 banks
+
+
+def extra_write(addrs, width):
+    extra = 0
+    for g in (W128 if width == 16 else W64):
+        per_bank = {}
+        for l in g:
+            for d in range(width // 4):
+                a = addrs[l] + 4 * d
+                per_bank.setdefault((a // 4) % 32, set()).add(a // 4)
+        extra += max(len(v) for v in per_bank.values()) - 1
+    return extra
+
+
+def epilogue(s):
+    """extra cycles per 64-row pass of the 128 x 32 wave-tile epilogues (csrc/xv_epilogue.h, xv_f6.h) under row swizzle s:
+    (pooling form: stage_f32 + two row4 sweeps, fp6 form: stage + row-per-lane read / write + read-back, split-blocked form)"""
+    stage = sum(extra_write([(fl * 16 + (l & 15)) * 128 + (((4 * ct + (l >> 4)) ^ s(fl * 16 + (l & 15))) << 4) for l in range(64)], 16)
+                for fl in range(4) for ct in range(2))
+    readback = sum(extra_cycles([(it * 8 + (l >> 3)) * 128 + (((l & 7) ^ s(it * 8 + (l >> 3))) << 4) for l in range(64)], 16)
+                   for it in range(8))
+    rowlane_r = sum(extra_cycles([l * 128 + ((q ^ s(l)) << 4) for l in range(64)], 16) for q in range(8))
+    rowlane_w = sum(extra_write([l * 128 + ((q ^ s(l)) << 4) for l in range(64)], 16) for q in range(8))
+    sbw = sum(extra_write([(fl * 16 + (l & 15)) * 128 + 8 * ((l >> 4) & 1) + (((lo + 2 * ct + ((l >> 4) >> 1)) ^ s(fl * 16 + (l & 15))) << 4)
+                           for l in range(64)], 8) for fl in range(4) for ct in range(2) for lo in (0, 4))
+    return stage + 2 * readback, stage + rowlane_r + rowlane_w + readback, sbw + readback
 
 
 def check_bijective():
@@ -95,4 +117,5 @@ if __name__ == "__main__":
         print("main reads, %d taps: extra LDS cycles per wave and channel block  old %4d   new %4d  (base %d)"
               % (taps, main_reads(taps, old_f), main_reads(taps, new_f1), taps * 8 * 4))
     print("cross reads (2 macro steps): old %d (base %d)   new %d (base %d)" % (cross_reads_old(), 16 * 14, cross_reads_new(), 16 * 14))
-    print("fp6 epilogue, row-per-lane phase (per pass): swizzle row&7 %d   (row>>1)&7 %d" % (epilogue_rowlane(lambda r: r & 7), epilogue_rowlane(old_f)))
+    for name, sw in (("row & 7", lambda r: r & 7), ("(row >> 1) & 7", old_f), ("(row & 7) ^ ((row >> 3) & 1)", lambda r: (r & 7) ^ ((r >> 3) & 1))):
+        print("epilogue scratch swizzle %-30s extra cycles per pass: pooling %3d  fp6 %3d  split-blocked %3d" % ((name,) + epilogue(sw)))

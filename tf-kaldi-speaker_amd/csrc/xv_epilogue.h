@@ -183,6 +183,15 @@ __device__ __forceinline__ void store_tile16_scalar(const GemmArgs& p, const f32
   }
 }
 
+// Chunk swizzle of the 128-byte scratch rows of the 128 x 32 wave-tile epilogues: (row & 7) ^ ((row >> 3) & 1).  LDS stores see 32
+// banks (one 128-byte row), so the eight consecutive rows of a ds_write_b128 lane group need eight different chunks: row & 7;
+// loads see 64 banks (two rows) and serve a ds_read_b128 in groups of lanes {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}: with
+// one row per lane (xv_f6.h) rows r and r + 24 / r + 12 of one parity would collide under row & 7 alone, bit 3 of the row
+// separates them.  Measured (SQ_LDS_BANK_CONFLICT per 64-row pass): row & 7 alone 0 / 128 / 64 for the pooling / fp6 / split-
+// blocked forms, (row >> 1) & 7 64 / 128 / 64; the split-blocked form's 64 are its ds_write_b64 (16 rows, one 8-byte half: 2-way
+// by construction).  tests/analysis/lds_bank_model.py.
+__device__ __forceinline__ int swz8(int row) { return (row & 7) ^ ((row >> 3) & 1); }
+
 // Ordering point between a wave's own LDS writes and its cross-lane read-back.  The scratch is private to the
 // wave and DS instructions of one wave execute in order, so no workgroup barrier (and no s_barrier at all) is
 // needed -- only that the compiler keeps the program order.
@@ -421,10 +430,7 @@ __device__ __forceinline__ void store_wave_tile_impl(const GemmArgs& p, const f3
 // LDS-staged epilogue of a 128-frame x 32-channel wave tile acc[ft][ct] (8 x 2 accumulator tiles of 16 frames x 16
 // channels, v_mfma_f32_16x16x32: lane & 15 -> frame, registers -> channels 4 * (lane >> 4) .. + 3; the "one wave per
 // 32-channel block" layout of the split kernels).  A row of the wave tile is exactly one SB block
-// (128 bytes) or 32 floats, so the scratch rows are 128 bytes (8 chunks, XOR-swizzled by (frame >> 1) & 7: two rows fill the
-// 64 banks, so rows r and r + 1 may share a swizzle, and then all four access patterns below -- 16 consecutive rows per
-// ds_write_b64 group, 8 per ds_write_b128 group, 2 rows x 8 chunks per read-back group, one row per lane in xv_f6.h -- are
-// conflict-free; with frame & 7 the b64 writes and the row-per-lane phase were 2-way: tests/analysis/lds_bank_model.py) and the
+// (128 bytes) or 32 floats, so the scratch rows are 128 bytes (8 chunks, XOR-swizzled by swz8(frame), below) and the
 // read-back hands 8 lanes one whole 128-byte line.  ROWS frames per pass (ROWS * 128 bytes of scratch per wave);
 // the fused statistics pooling needs ROWS == 64 (its partial slots are per 64-frame tile).
 template <int ACT, int ROWS, bool F16>
@@ -493,7 +499,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const int row = fl * 16 + c16;
-        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ ((row >> 1) & 7)) << 4)) = value4(acc[ps * FPP + fl][ct], ct, pre_act);
+        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ swz8(row)) << 4)) = value4(acc[ps * FPP + fl][ct], ct, pre_act);
       }
   };
   const int n = nbase + rchunk * 4;                      // read-back channels of this lane (fp32 forms)
@@ -509,7 +515,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       for (int it = 0; it < ROWS / 8; ++it) {
         const int row = it * 8 + rrow;
         const int m = mbase + ps * ROWS + row;
-        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ ((row >> 1) & 7)) << 4));
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ swz8(row)) << 4));
         bool zero;
         const int orow = out_row_pre(ps, it, zero);
         if (orow < 0) continue;
@@ -560,8 +566,8 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
             if (mbase + ps * ROWS + row < p.M) { ovf_bits(bad, h01); ovf_bits(bad, h23); }
           }
           char* rp = scratch + row * 128 + 8 * (g4 & 1);
-          *reinterpret_cast<uint2*>(rp + (((2 * ct + (g4 >> 1)) ^ ((row >> 1) & 7)) << 4)) = make_uint2(h01, h23);
-          *reinterpret_cast<uint2*>(rp + (((4 + 2 * ct + (g4 >> 1)) ^ ((row >> 1) & 7)) << 4)) = make_uint2(l01, l23);
+          *reinterpret_cast<uint2*>(rp + (((2 * ct + (g4 >> 1)) ^ swz8(row)) << 4)) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(rp + (((4 + 2 * ct + (g4 >> 1)) ^ swz8(row)) << 4)) = make_uint2(l01, l23);
           if constexpr (F16) __builtin_amdgcn_sched_barrier(0);   // one tile at a time: the fp16 conversions of eight
                                                                   // interleaved tiles do not fit the register budget
         }
@@ -571,7 +577,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
       for (int it = 0; it < ROWS / 8; ++it) {
         const int row = it * 8 + rrow;
         const int m = mbase + ps * ROWS + row;
-        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ ((row >> 1) & 7)) << 4));
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ swz8(row)) << 4));
         bool zero;
         const int orow = out_row_pre(ps, it, zero);
         if (zero) v = z;
@@ -596,7 +602,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
         for (int it = 0; it < ROWS / 8; ++it) {
           const int row = it * 8 + rrow;
           const int m = mbase + ps * ROWS + row;
-          f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ ((row >> 1) & 7)) << 4));
+          f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ swz8(row)) << 4));
           bool zero;
           const int orow = out_row_pre(ps, it, zero);
           if (zero) v = z;
@@ -612,7 +618,7 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
         const int my_utt = (mb + lane < p.M) ? p.pool_row2utt[mb + lane] : -1;
         const int tile64 = mb >> 6;
         auto row4 = [&](int t) -> f32x4 {
-          return *reinterpret_cast<const f32x4*>(scratch + t * 128 + ((rchunk ^ ((t >> 1) & 7)) << 4));
+          return *reinterpret_cast<const f32x4*>(scratch + t * 128 + ((rchunk ^ swz8(t)) << 4));
         };
         auto groups_sum = [&](f32x4 v) -> f32x4 {
 #pragma unroll
@@ -754,14 +760,14 @@ __device__ __forceinline__ void store_wave_tile_n32_att_impl(const GemmArgs& p, 
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const int row = fl * 16 + c16;
-        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ ((row >> 1) & 7)) << 4)) = value4(acc[ps * 4 + fl][ct], ct);
+        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ swz8(row)) << 4)) = value4(acc[ps * 4 + fl][ct], ct);
       }
     wave_lds_sync();
     const int mb = mbase + ps * 64;
     const int my_utt = (mb + lane < p.M) ? p.pool_row2utt[mb + lane] : -1;
     const int tile64 = mb >> 6;
     auto row4 = [&](int t) -> f32x4 {
-      return *reinterpret_cast<const f32x4*>(scratch + t * 128 + ((rchunk ^ ((t >> 1) & 7)) << 4));
+      return *reinterpret_cast<const f32x4*>(scratch + t * 128 + ((rchunk ^ swz8(t)) << 4));
     };
     auto groups_sum = [&](f32x4 v) -> f32x4 {
 #pragma unroll

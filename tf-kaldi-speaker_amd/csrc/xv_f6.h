@@ -1,5 +1,5 @@
 // Shared pieces of the two-unit split (XV_PREC_F16F6): block-scaled fp6 quantisation helpers and the epilogue that writes a layer's
-// output in the activation block format of gemm_f16f6.hip (f16 hi | fp6 codes of hi and lo | two E8M0 scales, 128 bytes per
+// output in the activation block format of gemm_f16f6.hip (f16 hi | fp6 codes of hi and lo | their E8M0 scales, 128 bytes per
 // (row, 32 channels)).  Used by gemm_f16f6.hip and by the F6-output instantiation of the multi-tap f16 kernel (gemm_bf16x3.hip).
 #pragma once
 #include "xv_epilogue.h"
@@ -74,12 +74,12 @@ __device__ __forceinline__ void store_wave_tile_n32_f6(const GemmArgs& p, const 
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = apply_act(fmaf(t[i], sc[ct][i], sh[ct][i]), p.act, al[i]);
         const int row = fl * 16 + c16;
-        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ ((row >> 1) & 7)) << 4)) = v;
+        *reinterpret_cast<f32x4*>(scratch + row * 128 + (((4 * ct + g4) ^ swz8(row)) << 4)) = v;
       }
     wave_lds_sync();
     {   // one row per lane
       char* rp = scratch + lane * 128;
-      const int sw = (lane >> 1) & 7;
+      const int sw = swz8(lane);
       float x[32];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -119,14 +119,15 @@ __device__ __forceinline__ void store_wave_tile_n32_f6(const GemmArgs& p, const 
         *reinterpret_cast<uint4*>(rp + ((q ^ sw) << 4)) = uint4{hw[4 * q], hw[4 * q + 1], hw[4 * q + 2], hw[4 * q + 3]};
       *reinterpret_cast<uint4*>(rp + ((4 ^ sw) << 4)) = uint4{ch[0], ch[1], ch[2], ch[3]};
       *reinterpret_cast<uint4*>(rp + ((5 ^ sw) << 4)) = uint4{cl[0], cl[1], cl[2], cl[3]};
-      *reinterpret_cast<uint4*>(rp + ((6 ^ sw) << 4)) = uint4{ch[4], ch[5], cl[4], cl[5]};
-      { const uint32_t sb2 = bh | (bl << 8); *reinterpret_cast<uint4*>(rp + ((7 ^ sw) << 4)) = uint4{sb2, sb2, sb2, sb2}; }   // four copies: the reader picks a dword by row (bank spread)
+      const uint32_t sc2 = bh | (bl << 8);                                            // chunk 6 / 7: code tail | scale dword | pad
+      *reinterpret_cast<uint4*>(rp + ((6 ^ sw) << 4)) = uint4{ch[4], ch[5], sc2, 0u};
+      *reinterpret_cast<uint4*>(rp + ((7 ^ sw) << 4)) = uint4{cl[4], cl[5], sc2, 0u};
     }
     wave_lds_sync();
 #pragma unroll 4
     for (int it = 0; it < ROWS / 8; ++it) {
       const int row = it * 8 + rrow;
-      f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ ((row >> 1) & 7)) << 4));
+      f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ swz8(row)) << 4));
       int r = rmap[it];
       const bool zero = r < -1;
       r = zero ? -r - 2 : r;

@@ -196,6 +196,7 @@ struct PlanStep {
   int M = 0;                    // GEMM rows to compute
   int rowmap = -1;              // index into plan rowmaps (conv layers)
   int64_t scratch_off = -1;     // per-step scratch (im2col rows / split-K partials), released after the step
+  int64_t scratch2_off = -1;    // two-unit layers: the K-split partials of the tail tiles (scratch_off holds the converted input)
   int ksplit = 1;               // split-K slices of a small-M fp32 GEMM, or of the tail M tiles of a bf16x3 GEMM
   int tail_mt = 0;              // bf16x3: M tiles computed K-split (gemm_bf16x3_tail_plan)
   bool fuse_pool = false;       // GEMM: emit pooling partials instead of activations; STAT_POOL: finalize only
@@ -800,13 +801,13 @@ int upload_layer(xv_handle* h, Layer& L) {
     XV_HIP(h, L.wfr.alloc(elems * 4));
     XV_HIP(h, hipMemcpy(L.wfr.p, fr.data(), elems * 4, hipMemcpyHostToDevice));
     if (L.use_f6) {
-      // gemm_f16f6_kernel operands (the scaled weights w * wscale, like the f16 halves above): taps padded to 8 with zeros.
+      // gemm_f6v2_kernel operands (the scaled weights w * wscale, like the f16 halves above): taps padded to 8 with zeros.
       //   main  [Npad/32][cin/32][8 taps][2 channel tiles][64 lanes = 16 * k-chunk + channel][8 x f16]
-      //   cross [Npad/32][cin/32][2 macro steps][2 channel tiles] x { 64 x 16 B q6(hi) | 64 x 16 B q6(lo) | 64 x (8 B hi tail | 8 B lo
-      //         tail) | 64 x 4 B scales (byte 0 hi, byte 1 lo) },  lane = 16 * (tap & 3) + channel: K group = tap inside the macro step
+      //   cross [Npad/32][cin/32][2 macro steps][2 terms: q6(w - f16(w)), q6(f16(w))][2 channel tiles] x { 64 x 16 B codes 0-15 |
+      //         64 x 16 B {codes 16-23, scale dword (E8M0 in byte 0), pad} },  lane = 16 * (tap & 3) + channel: K group = tap inside the macro step
       const int ncb = L.cin / 32;
-      const size_t main_ct = 64 * 16, cross_ct = 64 * 16 * 3 + 64 * 4;
-      std::vector<unsigned char> wm((size_t)(L.Npad / 32) * ncb * 8 * 2 * main_ct, 0), wx((size_t)(L.Npad / 32) * ncb * 2 * 2 * cross_ct, 0);
+      const size_t main_ct = 64 * 16, cross_ct = 2 * 64 * 16;
+      std::vector<unsigned char> wm((size_t)(L.Npad / 32) * ncb * 8 * 2 * main_ct, 0), wx((size_t)(L.Npad / 32) * ncb * 2 * 2 * 2 * cross_ct, 0);
       for (int n = 0; n < L.Npad; ++n) {
         const int nb = n >> 5, ct = (n >> 4) & 1, r16 = n & 15;
         for (int cb = 0; cb < ncb; ++cb)
@@ -821,13 +822,15 @@ int upload_layer(xv_handle* h, Layer& L) {
             }
             unsigned char* pm = &wm[((((size_t)nb * ncb + cb) * 8 + j) * 2 + ct) * main_ct];
             for (int kc = 0; kc < 4; ++kc) memcpy(pm + (16 * kc + r16) * 16, &hh[8 * kc], 16);
-            unsigned char* px = &wx[((((size_t)nb * ncb + cb) * 2 + (j >> 2)) * 2 + ct) * cross_ct];
             const int ln = 16 * (j & 3) + r16;
-            unsigned char c24[24], sc;
-            host_quant32(whi, c24, &sc);
-            memcpy(px + ln * 16, c24, 16); memcpy(px + 2048 + ln * 16, c24 + 16, 8); px[3072 + ln * 4] = sc;
-            host_quant32(wlo, c24, &sc);
-            memcpy(px + 1024 + ln * 16, c24, 16); memcpy(px + 2048 + ln * 16 + 8, c24 + 16, 8); px[3072 + ln * 4 + 1] = sc;
+            for (int term = 0; term < 2; ++term) {          // term 0 multiplies q6(hi) of the activations, term 1 q6(lo)
+              unsigned char* px = &wx[((((((size_t)nb * ncb + cb) * 2 + (j >> 2)) * 2 + term) * 2) + ct) * cross_ct];
+              unsigned char c24[24], sc;
+              host_quant32(term == 0 ? wlo : whi, c24, &sc);
+              memcpy(px + ln * 16, c24, 16);
+              memcpy(px + 1024 + ln * 16, c24 + 16, 8);
+              px[1024 + ln * 16 + 8] = sc;
+            }
           }
       }
       XV_HIP(h, L.wf6m.alloc(wm.size()));
@@ -1242,7 +1245,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
   for (size_t s = 0; s < order.size(); ++s) {
     const Op& op = h->ops[order[s]];
     PlanStep st;
-    int64_t step_scratch = 0;            // released once this step's outputs are placed
+    int64_t step_scratch = 0, step_scratch2 = 0;            // released once this step's outputs are placed
     st.op = order[s];
     st.to_out = (order[s] == node.op);
     st.rows_in = op.in0 >= 0 ? value_rows(h, op.in0, Fl, batch) : 0;
@@ -1294,6 +1297,13 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
         if (st.ksplit > 1) scratch = (int64_t)st.ksplit * st.M * L.Npad * 4;
       } else if (L.use_f6) {
         scratch = (st.rows_in + kSlackRows) * (int64_t)sb_ld(L.cin) * 4;      // the input in the block format of gemm_f16f6.hip
+        if (h->opt_tail_split && op.in1 <= 0) {
+          const int64_t part = gemm_bf16x3_tail_plan(st.M, L.Kpad, L.Npad, L.w, &st.tail_mt, &st.ksplit);
+          if (part > 0) {
+            step_scratch2 = align_up(part, kAlign);
+            st.scratch2_off = arena_alloc(step_scratch2);
+          }
+        }
       } else if (L.use_split && L.mode == 0 && op.out != fused_value && op.in1 <= 0 && h->opt_tail_split &&
                  order[s] != key_prod && order[s] != val_prod) {
         scratch = gemm_bf16x3_tail_plan(st.M, L.Kpad, L.Npad, L.w, &st.tail_mt, &st.ksplit);
@@ -1388,6 +1398,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
         if (h->ops[prev.op].kind == OP_ATT_SOFTMAX) st.att_s0_off = prev.att_s0_off;
     p->steps.push_back(st);
     if (step_scratch > 0) arena_free(st.scratch_off, step_scratch);
+    if (step_scratch2 > 0) arena_free(st.scratch2_off, step_scratch2);
     for (int in : {op.in0, op.in1})
       if (in > 0 && last_use[in] == (int)s) {
         if (vsize[in] > 0) { arena_free(voff[in], vsize[in]); vsize[in] = 0; }
@@ -1755,6 +1766,11 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           a.ldsbx = sb_ld(L.cin);
           a.Wfr = L.wf6m.p;
           a.Wx6 = L.wf6x.p;
+          if (st.tail_mt > 0 && st.scratch2_off >= 0) {
+            a.tail_mt = st.tail_mt;
+            a.ksplit = st.ksplit;
+            a.partial = reinterpret_cast<float*>(ws + st.scratch2_off);
+          }
           XV_HIP(h, launch_gemm_f16f6(a, s));
           break;
         }
