@@ -176,3 +176,56 @@ def test_extract_frame_stream_padding_and_chunking():
     assert extract_frame.split_plain(230, 100) == [(0, 100), (100, 100), (200, 30)]
     a = extract_frame.build_parser().parse_args(["--node", "tdnn4_relu", "m", "r", "w"])
     assert (a.gpu, a.min_chunk_size, a.chunk_size, a.node) == (-1, 25, 10000, "tdnn4_relu")
+
+
+def test_asm_guard_catches_an_in_flight_register_and_a_compiler_load(repo_root):
+    """tools/asm_guard.py (run by __graft_entry__.build on the emitted gfx950 assembly of the hand-scheduled kernels): a register
+    that is the destination of a load still in flight must not be touched before the counted wait that retires it -- also across
+    a loop's back edge -- and the K loop must contain no vector-memory instruction outside the kernels' asm statements."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("asm_guard", os.path.join(repo_root, "tools", "asm_guard.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    ok = """
+	s_waitcnt vmcnt(0)
+.LBB0_1:
+	;;#ASMSTART
+	global_load_dwordx4 v[10:13], v1, s[2:3] offset:0
+	;;#ASMEND
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	v_mfma_f32_16x16x32_f16 v[20:23], v[14:17], v[30:33], v[20:23]
+	;;#ASMSTART
+	global_load_dwordx4 v[14:17], v1, s[2:3] offset:1024
+	;;#ASMEND
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	v_mfma_f32_16x16x32_f16 v[20:23], v[10:13], v[30:33], v[20:23]
+	s_cbranch_scc1 .LBB0_1
+	s_endpgm
+""".splitlines()
+    viol, st = g.check_kernel(ok)
+    assert viol == [] and st["mfma"] == 2 and st["asm_loads"] == 1, (viol, st)
+    # the same loop with the second wait one too lax: on the NEXT iteration v[10:13] is reloaded while ... no: the MFMA reads
+    # v[10:13] while its load from the top of this iteration may still be in flight
+    lax = [l.replace("s_waitcnt vmcnt(1)", "s_waitcnt vmcnt(2)") if i > 10 else l for i, l in enumerate(ok)]
+    viol, _ = g.check_kernel(lax)
+    assert any("v[10" in v or "[10," in v for v in viol), viol
+    # a compiler-generated spill reload between the MFMAs
+    spill = list(ok)
+    spill.insert(10, "	scratch_load_dword v40, off, off offset:16")
+    viol, st = g.check_kernel(spill)
+    assert st["compiler_vmem_in_loop"] == 1 and any("compiler-generated" in v for v in viol)
+    # the round-2 fault: a v_mov into a destination right behind its load (block-local form)
+    reuse = list(ok)
+    reuse.insert(6, "	v_mov_b32_e32 v11, v3")
+    assert any("v[11]" in v for v in g.check_kernel_local(reuse)[0])
+    assert any("v[11]" in v for v in g.check_kernel(reuse)[0])
+    # and the report of the real build exists with zero violations for every hand-scheduled kernel
+    rep = os.path.join(repo_root, "profiles", "r03", "asm_guard.txt")
+    if os.path.isfile(rep):
+        rows = [l for l in open(rep) if l.startswith("_Z")]
+        assert len(rows) >= 20 and all(l.rstrip().endswith("violations 0") for l in rows)
+        assert sum("gemm_f6v2_kernel" in l and "all-paths" in l for l in rows) == 4

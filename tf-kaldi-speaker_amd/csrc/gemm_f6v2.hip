@@ -285,6 +285,10 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     __syncthreads();                      // every wave is done reading slab cb; slab cb + 1 landed long ago (waits above)
   };
   for (int cb = cb_begin; cb + 1 < cb_end; ++cb) body(cb, std::false_type());
+  // (hand-over to the straight-line copy: an empty asm over the accumulators ends their live ranges here, so that the allocator may
+  // re-assign them for the copy instead of spilling one tile across the seam -- it did, in the 5-tap form)
+#pragma unroll
+  for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(acc[g][0]), "+v"(acc[g][1]));
   body(cb_end - 1, std::true_type());
   // (nothing is in flight here: the last body waited for its last set with vmcnt(0) and its end-of-block barrier has been passed
   // by every wave, so the slab buffers may become the epilogue's scratch)
