@@ -16,8 +16,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement).  `value` is the
                  1 thread, batch 1) run as nj = min(host cores, 32) fresh processes side by side
                  (run_extract_embeddings.sh:3,68) for a bounded time; N = 1 only;
   value_reps   : min / median / max of 5 more repetitions of the same K-step timed region;
-  e2e_value    : host numpy -> pinned staging -> H2D -> kernels -> D2H (Trainer.predict_list), N = 1 only;
+  e2e_value    : host numpy -> pinned staging -> H2D -> kernels -> D2H with two batches in flight (Trainer.submit_list / collect);
+                 e2e_sync_value: one blocking Trainer.predict_list per batch; N = 1 only;
   cli          : ark -> ark through the command-line driver in a fresh process, N = 1 only;
+  launcher     : the config-4 set through run_extract.py (the run_extract_embeddings.sh counterpart), nj = 1, wall clock incl.
+                 process start-up, N = 1 only;
   config4      : BASELINE configs[3] / SURVEY 8(d) config 4 -- a FIXED set of 8192 utterances, T ~ U[200,1000]
                  (seed 2024), LPT-sharded over WORLD_SIZE ranks, resident in HBM, ragged batches; utt/s and
                  frames/s of the whole set (strong scaling), frames per rank.  Runs at every N.
@@ -194,18 +197,77 @@ def cli_leg(weights, params, dim, frames, n_utts, precision):
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": r.stderr[-300:]}
-        loop = None
+        loop, waits = None, None
         for line in r.stderr.splitlines():
             if line.startswith("Extracted ") and " in " in line:
                 loop = float(line.rsplit(" in ", 1)[1].split()[0])
+            if "driver loop:" in line:
+                waits = line.split("driver loop:", 1)[1].strip()
         size = os.path.getsize(os.path.join(tmp, "xvector.ark"))
     finally:
         subprocess.call(["rm", "-rf", tmp])
     return {"utterances": n_utts, "wall_s": round(wall, 2), "loop_s": loop,
             "value": round(n_utts / loop, 1) if loop else None, "value_incl_startup": round(n_utts / wall, 1),
-            "unit": "utterances/s", "out_bytes": size,
+            "unit": "utterances/s", "out_bytes": size, "loop_waits": waits,
             "note": "value = utterances / time of the driver's read-embed-write loop; value_incl_startup adds process "
                     "start-up, model upload and the first-touch of the GPU"}
+
+
+def launcher_leg(weights, params, dim, n_utts, precision):
+    """The config-4 set (T ~ U[200,1000], seed 2024) through the LAUNCHER -- `run_extract.py` = run_extract_embeddings.sh:
+    stage 0 (shards, one fresh extraction process per job), stage 1 (ordered scp merge), stages 2-3 (speaker means, length norm) --
+    with nj = one job on this GPU, wall clock of the whole command incl. both process start-ups: what a job costs before an
+    8-GPU node ever runs eight of them side by side."""
+    from tf_kaldi_speaker_amd import kaldi_io, model_io, sharding
+    tmp = tempfile.mkdtemp(prefix="xvlaunch_", dir="/tmp")
+    try:
+        model_dir = os.path.join(tmp, "exp")
+        model_io.save_model(model_dir, dict(params.dict), dim, weights, step=1)
+        data = os.path.join(tmp, "data")
+        os.makedirs(data)
+        lens = sharding.config4_lengths(n=n_utts)
+        base = np.random.RandomState(7).standard_normal((int(lens.max()) + 64, dim)).astype(np.float32)
+        ark = os.path.join(data, "feats.ark")
+        with open(ark, "wb") as f, open(os.path.join(data, "feats.scp"), "w") as scp, \
+                open(os.path.join(data, "utt2num_frames"), "w") as u2n, open(os.path.join(data, "spk2utt"), "w") as s2u:
+            spk = {}
+            for i, t in enumerate(lens):
+                key = "spk%03d-utt%06d" % (i % 128, i)
+                f.write((key + " ").encode())
+                scp.write("%s %s:%d\n" % (key, ark, f.tell()))
+                kaldi_io.write_mat(f, base[i % 64:i % 64 + int(t)], key="")
+                u2n.write("%s %d\n" % (key, int(t)))
+                spk.setdefault("spk%03d" % (i % 128), []).append(key)
+            for k in sorted(spk):
+                s2u.write("%s %s\n" % (k, " ".join(spk[k])))
+        env = dict(os.environ)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        out = os.path.join(tmp, "xv")
+        cmd = [sys.executable, "-m", "tf_kaldi_speaker_amd.run_extract", "--nj", "1", "--gpus", "0", "--apply-vad", "false",
+               "--cmn-window", "0", "--min-chunk-size", "25", "--node", params.embedding_node, "--precision", precision,
+               "--batch-frames", "153600", model_dir, data, out]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": (r.stdout + r.stderr)[-400:]}
+        loop = None
+        try:
+            for line in open(os.path.join(out, "log", "extract.1.log")):
+                if line.startswith("Extracted ") and " in " in line:
+                    loop = float(line.rsplit(" in ", 1)[1].split()[0])
+        except OSError:
+            pass
+        n_out = sum(1 for _ in open(os.path.join(out, "xvector.scp")))
+    finally:
+        subprocess.call(["rm", "-rf", tmp])
+    frames = int(lens.sum())
+    return {"workload": "%d utterances, T ~ U[200,1000] seed 2024, through run_extract.py (nj 1, one GPU, stages 0-3)" % n_utts,
+            "vectors": n_out, "wall_s": round(wall, 2), "job_loop_s": loop,
+            "value_incl_startup": round(n_utts / wall, 1), "frames_per_s_incl_startup": round(frames / wall, 1),
+            "value_job_loop": round(n_utts / loop, 1) if loop else None,
+            "frames_per_s_job_loop": round(frames / loop, 1) if loop else None, "unit": "utterances/s",
+            "note": "wall = launcher + job process start-up, model upload, extraction loop, merge and the two post stages"}
 
 
 def config4_leg(tr, args, dist, world, rank, dev, weights, params):
@@ -401,16 +463,28 @@ def main():
     c4 = None
     if extra and tdnn_default and args.c4_steps > 0:
         c4 = config4_leg(tr, args, dist, world, rank, dev, weights, params)
-    e2e_rate = None
+    e2e_rate = e2e_sync = None
     if extra and n_gpus == 1 and rank == 0:
-        tr.predict_list(utts)                              # warm-up (pinned staging buffer)
-        n_e2e = max(3, args.steps // 2)
-        calls = []
+        # host numpy -> pinned staging -> H2D -> kernels -> D2H.  e2e_value: the caller keeps two batches in flight
+        # (Trainer.submit_list / collect: what the command-line driver does); e2e_sync_value: one blocking predict_list per batch
+        for _ in range(3):
+            tr.predict_list(utts)                          # warm-up (staging slots, copy stream)
+        n_e2e = max(8, args.steps)
+        t1 = time.perf_counter()
+        tickets = []
         for i in range(n_e2e):
+            tickets.append(tr.submit_list(utts))
+            if len(tickets) == 2:
+                tr.collect(tickets.pop(0))
+        while tickets:
+            tr.collect(tickets.pop(0))
+        e2e_rate = n_e2e * args.batch / (time.perf_counter() - t1)
+        calls = []
+        for i in range(max(3, args.steps // 2)):
             t1 = time.perf_counter()
             tr.predict_list(utts)
             calls.append(time.perf_counter() - t1)
-        e2e_rate = args.batch / sorted(calls)[len(calls) // 2]     # median call: one stalled call must not set the rate
+        e2e_sync = args.batch / sorted(calls)[len(calls) // 2]     # median call: one stalled call must not set the rate
     result = None
     if rank == 0:
         total_utts = n_gpus * args.batch * args.steps
@@ -470,6 +544,7 @@ def main():
             result["value_reps"] = {"n": len(rates), "min": round(rates[0], 1), "median": round(rates[len(rates) // 2], 1),
                                     "max": round(rates[-1], 1), "what": "repetitions of the same %d-step timed region" % args.steps}
         result["e2e_value"] = round(e2e_rate, 1) if e2e_rate else None
+        result["e2e_sync_value"] = round(e2e_sync, 1) if e2e_sync else None
         result["value_bf16x3"] = round(bf_rate, 1) if bf_rate else None
         result["config4"] = c4
     tr.close()
@@ -484,6 +559,12 @@ def main():
                 result["cli"] = cli_leg(weights, params, args.dim, args.frames, args.cli_utts, precision)
             except Exception as e:              # the extra leg must not cost the bench line
                 result["cli"] = {"error": str(e)[:300]}
+        result["launcher"] = None
+        if extra and n_gpus == 1 and tdnn_default and not args.varlen and args.c4_utts > 0:
+            try:
+                result["launcher"] = launcher_leg(weights, params, args.dim, args.c4_utts, precision)
+            except Exception as e:
+                result["launcher"] = {"error": str(e)[:300]}
         if args.cpu_seconds > 0 and n_gpus == 1:
             result["cpu_baseline"] = cpu_baseline(weights, params, args.dim, args.frames, args.cpu_seconds, args.cpu_nj)
         else:

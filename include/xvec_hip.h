@@ -282,6 +282,11 @@ void xv_ark_close(xv_ark_reader* r);
 int64_t xv_ark_format_vectors(const char* keys, int n, const float* data, int dim, int64_t ld, char* out,
                               int64_t out_capacity);
 
+/* Copy n blocks (src[i], nbytes[i] bytes) back to back into dst with up to `threads` threads: the staging copy of a ragged batch
+ * that arrives as separate [T_i, d] matrices (Trainer.predict, model/trainer.py:886-913, called once per utterance by
+ * extract.py:89; here once per batch).  Returns the number of bytes copied or a negative xv_status. */
+int64_t xv_pack_rows(const void* const* src, const int64_t* nbytes, int n, void* dst, int threads);
+
 /* CRC-32C (Castagnoli) of n bytes continuing from `crc` (0 to start): the checksum of TensorFlow checkpoint-V2 index blocks and
  * tensors (the weight source of model/trainer.py:277-295; tf-kaldi-speaker_amd/tf_checkpoint.py applies the LevelDB mask). */
 uint32_t xv_crc32c(uint32_t crc, const void* data, int64_t n);

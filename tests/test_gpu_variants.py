@@ -405,3 +405,41 @@ def test_handles_release_their_device_memory():
     torch.cuda.empty_cache()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, (free0, free1)        # one cycle uploads > 60 MB of weights
+
+
+def test_pipelined_host_interface_equals_blocking_calls():
+    """Trainer.submit_list / collect (two batches in flight: H2D of batch i + 1 on a copy stream beside the kernels of batch i,
+    range flags read out in stream order) must return exactly what one blocking predict_list per batch returns, in any
+    interleaving the slots allow, for ragged batches of different sizes; a fourth outstanding ticket is refused; an overflow in
+    one batch is reported for THAT batch only."""
+    from tf_kaldi_speaker_amd import synth
+    params = dict(synth.TDNN_STAT_PARAMS)
+    weights = synth.synth_weights(params, 30, seed=0)
+    rs = np.random.RandomState(4)
+    batches = [synth.synth_features(n, [int(t) for t in rs.randint(15, 400, size=n)], 30, seed=60 + n) for n in (5, 64, 1, 17, 33, 9)]
+    tr = _trainer(params, weights, 30, "f16f6")
+    want = [tr.predict_list(b) for b in batches]
+    got, tickets = [], []
+    for b in batches:
+        tickets.append(tr.submit_list(b))
+        if len(tickets) == 2:
+            got.append(tr.collect(tickets.pop(0)))
+    t3 = tr.submit_list(batches[0])
+    t4 = tr.submit_list(batches[1])
+    with pytest.raises(RuntimeError):
+        tr.submit_list(batches[2])                        # NUM_SLOTS = 3 outstanding
+    got.append(tr.collect(tickets.pop(0)))
+    assert np.array_equal(tr.collect(t3), want[0])
+    assert np.array_equal(tr.collect(t4), want[1])
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    bad = [u.copy() for u in batches[3]]
+    bad[2][5, 7] = 1.0e5                                   # beyond the fp16 range
+    t_ok, t_bad, = tr.submit_list(batches[2]), tr.submit_list(bad)
+    assert np.array_equal(tr.collect(t_ok), want[2])
+    with pytest.raises(FloatingPointError):
+        tr.collect(t_bad)
+    assert np.array_equal(tr.predict_list(batches[4]), want[4])         # the flag was cleared in stream order
+    frames = tr.collect(tr.submit_list(batches[0], node="tdnn3_relu"))     # frame-level node: list of [T_i - 14, 512]
+    assert [f.shape[0] for f in frames] == [u.shape[0] - 14 for u in batches[0]]
+    tr.close()

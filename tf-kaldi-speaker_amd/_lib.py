@@ -27,7 +27,7 @@ EXPORTS = ["xv_version", "xv_create", "xv_set_tensor", "xv_finalize", "xv_set_op
            "xv_plan_create", "xv_plan_query", "xv_plan_destroy", "xv_forward", "xv_profile_begin", "xv_profile_end",
            "xv_destroy", "xv_last_error",
            "xv_frontend_cmn_select", "xv_length_normalize", "xv_speaker_mean",
-           "xv_ark_open", "xv_ark_open_scp", "xv_ark_scp_count", "xv_ark_scp_shapes", "xv_ark_next_batch", "xv_ark_pending_shape", "xv_ark_skipped", "xv_ark_set_copy_threads", "xv_ark_error", "xv_ark_close", "xv_ark_format_vectors", "xv_crc32c"]
+           "xv_ark_open", "xv_ark_open_scp", "xv_ark_scp_count", "xv_ark_scp_shapes", "xv_ark_next_batch", "xv_ark_pending_shape", "xv_ark_skipped", "xv_ark_set_copy_threads", "xv_ark_error", "xv_ark_close", "xv_ark_format_vectors", "xv_crc32c", "xv_pack_rows"]
 
 
 class ModelDesc(C.Structure):
@@ -121,10 +121,12 @@ def load():
     lib.xv_ark_format_vectors.argtypes = [vp, i32, vp, i32, i64, vp, i64]
     lib.xv_ark_format_vectors.restype = i64
     lib.xv_crc32c.argtypes = [C.c_uint32, vp, i64]
+    lib.xv_pack_rows.argtypes = [vp, vp, i32, vp, i32]
+    lib.xv_pack_rows.restype = i64
     lib.xv_crc32c.restype = C.c_uint32
     for n in EXPORTS:
         if n not in ("xv_version", "xv_last_error", "xv_plan_destroy", "xv_destroy", "xv_ark_skipped", "xv_ark_error",
-                     "xv_ark_close", "xv_ark_format_vectors", "xv_ark_scp_count", "xv_crc32c"):
+                     "xv_ark_close", "xv_ark_format_vectors", "xv_ark_scp_count", "xv_crc32c", "xv_pack_rows"):
             getattr(lib, n).restype = i32
     _lib = lib
     return lib

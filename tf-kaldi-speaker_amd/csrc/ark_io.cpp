@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 
@@ -566,6 +567,43 @@ int64_t xv_ark_format_vectors(const char* keys, int n, const float* data, int di
     k = e + 1;
   }
   return pos;
+}
+
+// Pack n row blocks (src[i], nbytes[i]) back to back into dst with a few threads: the staging copy of Trainer.submit_list (a ragged
+// batch arrives as a list of separate [T_i, d] matrices; 9 MB per 256 x 300 frames, memcpy-bound on one core).  Returns the bytes copied.
+int64_t xv_pack_rows(const void* const* src, const int64_t* nbytes, int n, void* dst, int threads) {
+  if (!src || !nbytes || !dst || n < 0) return XV_ERR_INVALID;
+  std::vector<int64_t> start((size_t)n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    if (nbytes[i] < 0 || (!src[i] && nbytes[i] > 0)) return XV_ERR_INVALID;
+    start[i + 1] = start[i] + nbytes[i];
+  }
+  const int64_t total = start[n];
+  int nt = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+  if (total < ((int64_t)1 << 20)) nt = 1;
+  auto work = [&](int64_t lo, int64_t hi) {            // bytes [lo, hi) of the concatenation
+    int i = (int)(std::upper_bound(start.begin(), start.end(), lo) - start.begin()) - 1;
+    while (lo < hi && i < n) {
+      const int64_t a = lo - start[i];
+      const int64_t len = std::min(hi, start[i + 1]) - lo;
+      if (len > 0) memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src[i]) + a, (size_t)len);
+      lo += len > 0 ? len : 0;
+      ++i;
+    }
+  };
+  if (nt == 1) {
+    work(0, total);
+  } else {
+    std::vector<std::thread> th;
+    const int64_t share = ((total + nt - 1) / nt + 63) & ~(int64_t)63;
+    for (int t = 1; t < nt; ++t) {
+      const int64_t lo = share * t, hi = std::min(lo + share, total);
+      if (lo < hi) th.emplace_back(work, lo, hi);
+    }
+    work(0, std::min(share, total));
+    for (auto& x : th) x.join();
+  }
+  return total;
 }
 
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of `n` bytes, continuing from `crc` (0 to start): the checksum of the blocks

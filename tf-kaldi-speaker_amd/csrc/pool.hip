@@ -426,17 +426,21 @@ __global__ void im2col_sb_kernel(const float* __restrict__ x, int64_t ldx, int c
     *reinterpret_cast<uint32_t*>(blk + 64) = lo;
   }
   // fp16 split: the other end of the range.  Hidden activations are kept at a per-layer power-of-two scale (GemmArgs::sb_mul), the
-  // features are whatever the caller sends: the largest magnitude of the batch goes to flag word 1 (bits of a non-negative float
-  // order like integers) and the host refuses a batch whose features all sit below 2^-8, where the low halves are subnormal
-  // and even the largest value keeps fewer than 17 bits (xv_check_overflow).
+  // features are whatever the caller sends: every workgroup leaves the largest magnitude it staged in its own word behind the flag
+  // words (no atomics: 19 200 same-address atomics per batch took 0.2 ms, four times the layer this staging feeds -- and a version
+  // that skipped the atomic below the current maximum paid them again after every reset); flags_snapshot_kernel / xv_check_overflow
+  // reduce the words, and the host refuses a batch whose features all sit below 2^-8, where the low halves are subnormal and even
+  // the largest value keeps fewer than 17 bits.
   if (f16 && ovf) {
+    __shared__ float wmax[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    // (one address for the whole launch: the atomic is only issued by a wave that would raise the maximum -- a handful per
-    // batch; unconditional, 19 200 same-address atomics took 0.23 ms, four times the layer the staging feeds)
-    if ((threadIdx.x & 63) == 0 && mx > 0.f && mx <= 3.0e38f &&
-        __float_as_int(mx) > __builtin_nontemporal_load(ovf + 1))
-      atomicMax(ovf + 1, __float_as_int(mx));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      reinterpret_cast<float*>(ovf + kFlagWords)[blockIdx.x] = (m <= 3.0e38f) ? m : 0.f;
+    }
   }
 }
 
@@ -444,7 +448,7 @@ hipError_t launch_im2col_sb(const float* x, int64_t ldx, int cin, int w, int64_t
                             int* ovf, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   const int64_t total = rows * (ldsb >> 1);
-  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  const int blocks = (int)((total + 255) / 256 > kFeatMaxSlots ? kFeatMaxSlots : (total + 255) / 256);
   hipLaunchKernelGGL(im2col_sb_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, cin, w * cin, rows,
                      static_cast<char*>(out_sb), ldsb, f16, ovf);
   return hipGetLastError();
@@ -494,6 +498,32 @@ __global__ __launch_bounds__(256) void l2_scale_kernel(const float* __restrict__
 hipError_t launch_l2_scale(const float* x, int64_t rows, int C, float factor, float* y, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   hipLaunchKernelGGL(l2_scale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, C, factor, y);
+  return hipGetLastError();
+}
+
+// fp16 range flags -> pinned host memory, and cleared for the next forward: ONE small kernel in stream order.  (A memcpy D2H plus a
+// memset are two engine switches between two forwards: together with the result copy they cost 0.15 ms of device time per 1.27 ms
+// batch -- tools/pipeline_probe.py.)
+__global__ void flags_snapshot_kernel(int* __restrict__ dev, int* __restrict__ host) {
+  float* part = reinterpret_cast<float*>(dev + kFlagWords);          // per-workgroup feature maxima of the staging kernel
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < kFeatMaxSlots; i += 64) {
+    mx = fmaxf(mx, part[i]);
+    part[i] = 0.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (threadIdx.x == 0) {
+    host[0] = dev[0];
+    host[1] = __float_as_int(fmaxf(mx, __int_as_float(dev[1])));
+    dev[0] = 0;
+    dev[1] = 0;
+    __threadfence_system();
+  }
+}
+
+hipError_t launch_flags_snapshot(int* dev, int* host, hipStream_t s) {
+  hipLaunchKernelGGL(flags_snapshot_kernel, dim3(1), dim3(64), 0, s, dev, host);
   return hipGetLastError();
 }
 

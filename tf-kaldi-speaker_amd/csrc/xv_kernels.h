@@ -10,6 +10,9 @@ namespace xv {
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_PRELU = 3, ACT_TANH = 4 };
 
 constexpr float kLreluAlpha = 0.2f;       // tf.nn.leaky_relu default (model/tdnn.py:33)
+// fp16 range guard buffer of a handle: kFlagWords ints ([0] overflow flag, [1] bits of a feature maximum carried over), then
+// kFeatMaxSlots floats: the largest feature magnitude each workgroup of the feature staging kernel saw since the last read-out
+constexpr int kFlagWords = 4, kFeatMaxSlots = 8192;
 constexpr float kVarFloor = 1e-12f;       // VAR2STD_EPSILON (model/pooling.py:6)
 
 // One "overlapping-row" GEMM:  Y[rowmap[m], n] = act((sum_k A[m,k] * Wt[n,k]) * scale[n] + shift[n])
@@ -236,6 +239,8 @@ hipError_t launch_l2_scale(const float* x, int64_t rows, int C, float factor, fl
 // transposed copy [B,H,L]-style attention weights: out[b][h][t] from scores [rows,H] (uniform L only)
 hipError_t launch_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int cols,
                          hipStream_t s);
+// fp16 range flags (2 ints) -> device-accessible host memory, then cleared; one kernel
+hipError_t launch_flags_snapshot(int* dev, int* host, hipStream_t s);
 hipError_t launch_att_weights_out(const float* scores, int H, const int32_t* off0, int B, int ctx,
                                   float* out, hipStream_t s);
 

@@ -1002,8 +1002,8 @@ int xv_finalize(xv_handle* h) {
       XV_HIP(h, hipMemcpy(h->post_vec.p, vec.data(), vec.size() * sizeof(float), hipMemcpyHostToDevice));
     }
   }
-  XV_HIP(h, h->ovf_flag.alloc(4 * sizeof(int)));
-  XV_HIP(h, hipMemset(h->ovf_flag.p, 0, 4 * sizeof(int)));
+  XV_HIP(h, h->ovf_flag.alloc((kFlagWords + kFeatMaxSlots) * sizeof(int)));
+  XV_HIP(h, hipMemset(h->ovf_flag.p, 0, (kFlagWords + kFeatMaxSlots) * sizeof(int)));
   XV_HIP(h, hipDeviceSynchronize());
   for (auto& kv : h->tensors) { kv.second.data.clear(); kv.second.data.shrink_to_fit(); }
   h->finalized = true;
@@ -1027,9 +1027,11 @@ int xv_check_overflow(xv_handle* h, int reset) {
   if (!h) return fail(nullptr, XV_ERR_INVALID, "xv_check_overflow: null handle");
   if (!h->finalized || !h->ovf_flag.p) return 0;
   DeviceGuard g(h->device);
-  int32_t v[2] = {0, 0};
-  XV_HIP(h, hipMemcpy(v, h->ovf_flag.p, sizeof(v), hipMemcpyDeviceToHost));
-  if ((v[0] || v[1]) && reset) XV_HIP(h, hipMemset(h->ovf_flag.p, 0, sizeof(v)));
+  std::vector<int32_t> w((size_t)kFlagWords + kFeatMaxSlots);
+  XV_HIP(h, hipMemcpy(w.data(), h->ovf_flag.p, w.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  int32_t v[2] = {w[0], w[1]};
+  for (int i = 0; i < kFeatMaxSlots; ++i) v[1] = std::max(v[1], w[(size_t)kFlagWords + i]);     // non-negative floats order like ints
+  if (reset) XV_HIP(h, hipMemset(h->ovf_flag.p, 0, w.size() * sizeof(int32_t)));
   return xv_flags_decode(v);
 }
 
@@ -1049,8 +1051,16 @@ int xv_flags_async(xv_handle* h, int32_t* host_flags, void* stream) {
   if (!h->finalized || !h->ovf_flag.p) { host_flags[0] = host_flags[1] = 0; return XV_OK; }
   DeviceGuard g(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  XV_HIP(h, hipMemcpyAsync(host_flags, h->ovf_flag.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  XV_HIP(h, hipMemsetAsync(h->ovf_flag.p, 0, 2 * sizeof(int32_t), s));
+  // pinned (device-accessible) host memory: one small kernel writes the words there and clears them; anything else: a copy + a memset
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, host_flags) == hipSuccess && attr.type == hipMemoryTypeHost) {
+    XV_HIP(h, launch_flags_snapshot(static_cast<int*>(h->ovf_flag.p), host_flags, s));
+    return XV_OK;
+  }
+  (void)hipGetLastError();               // (an unregistered pointer makes the query fail: not an error of ours)
+  // pageable destination: the words are reduced into device word 1 first, then copied
+  XV_HIP(h, launch_flags_snapshot(static_cast<int*>(h->ovf_flag.p), static_cast<int*>(h->ovf_flag.p) + 2, s));
+  XV_HIP(h, hipMemcpyAsync(host_flags, static_cast<int*>(h->ovf_flag.p) + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   return XV_OK;
 }
 

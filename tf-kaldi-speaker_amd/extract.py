@@ -40,8 +40,9 @@ def build_parser():
                              "final embedding. L2 normalizaion will be applied before the averaging if specified.")
     parser.add_argument("-n", "--normalize", action="store_true", help="Normalize the embedding before averaging and output.")
     parser.add_argument("--node", type=str, default="", help="The node to output the embeddings.")
-    parser.add_argument("--batch-frames", type=int, default=76800,
-                        help="Frames packed into one device batch (extension; 76800 = 256 utterances x 300 frames).")
+    parser.add_argument("--batch-frames", type=int, default=153600,
+                        help="Frames packed into one device batch (extension; 153600 = 512 utterances x 300 frames: the fixed cost per "
+                             "batch -- plan look-up, pipeline hand-over -- is paid half as often as with 76800).")
     parser.add_argument("--precision", type=str, default="", help="f32 | bf16x3 | f16x3 | f16f6 (extension; default: library default)")
     parser.add_argument("--scp-input", action="store_true",
                         help="Accept `scp:<file>` as the rspecifier and read its records natively by seeking (extension; "
@@ -234,19 +235,26 @@ def _vad_lookup(vad_rspecifier):
 
 def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normalize, batch_frames, cmn_window=0,
                vad_rspecifier=""):
-    """Fast path of the driver: the native batch reader (csrc/ark_io.cpp) parses ark records straight into
-    pinned staging buffers on a background thread (outside the GIL); this thread enqueues H2D + forward + D2H of batch i
-    and only then waits for, normalises and writes batch i - 1, so the device always has the next batch queued while
-    the host formats vectors.  Batches containing an utterance longer than chunk_size go through the generic chunking
-    path on views of the same buffer."""
+    """Fast path of the driver, three stages that overlap:
+      reader thread   the native batch reader (csrc/ark_io.cpp) parses ark records straight into pinned staging buffers
+                      (outside the GIL);
+      this thread     copies batch i to the device on a COPY stream (beside the kernels of batch i - 1), enqueues the forward,
+                      the copy of the result into a pinned slot and the read-out of the fp16 range flags (xv_flags_async: no
+                      host synchronisation), then waits for batch i - 2 and hands it over;
+      writer thread   range check, L2 normalisation, vector formatting (native, outside the GIL) and the write.
+    Two batches are in flight on the device at any time, so neither the host-side output work nor the H2D copy of the next batch
+    leaves it idle.  Batches containing an utterance longer than chunk_size, and the front-end path, go through the synchronous
+    code on views of the same buffers (in order: everything in flight is written first)."""
     import queue
     import threading
     import torch
     from . import native_ark
     cap = (batch_frames + 65536) * 64
-    # four staging buffers: one being filled, one queued, one in flight on the device (its H2D may not have run yet when
-    # the next batch is taken from the queue), one spare -- batch i is written out before batch i + 2 is taken
-    pins = [torch.empty(cap, dtype=torch.float32, pin_memory=True) for _ in range(4)]
+    NPIN, NSLOT, KEEP = 6, 5, 2
+    # six staging buffers: the reader is at most two batches ahead (one being filled, one queued), three are in flight on the
+    # device or being copied (KEEP + the one just taken), one spare.  Five result slots: KEEP in flight, one queued for the
+    # writer, one the writer is working on, one for the batch being enqueued.
+    pins = [torch.empty(cap, dtype=torch.float32, pin_memory=True) for _ in range(NPIN)]
     frontend = cmn_window > 0 or bool(vad_rspecifier)
     vad_of = _vad_lookup(vad_rspecifier) if vad_rspecifier else None
     # with the front-end on, the min-length rule applies to the lengths after frame selection
@@ -266,81 +274,153 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
     threading.Thread(target=producer, daemon=True).start()
     done = extra_skipped = 0
     dev_index = trainer._device_index
-    pending = []                          # [(keys, pinned embeddings, event)]: batches enqueued on the device, oldest first
-    emb_pins = [None, None]               # flat pinned result buffers, used alternately
+    devname = "cuda:%d" % dev_index
+    pending = []                          # batches enqueued on the device, oldest first: (keys, pinned embeddings, pinned flags, event)
+    wq = queue.Queue(maxsize=1)
+    werr = []
+
+    def consumer():
+        while True:
+            item = wq.get()
+            try:
+                if item is None:
+                    return
+                if werr:
+                    continue                            # drain after a failure: the main thread raises it
+                keys_p, host_p, flags_p = item
+                emb = host_p.numpy()
+                trainer.raise_on_flags(trainer.decode_flags(flags_p), emb)
+                if normalize:
+                    emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
+                writer.write(keys_p, emb)
+            except BaseException as e:
+                werr.append(e)
+            finally:
+                wq.task_done()
+
+    wthread = threading.Thread(target=consumer, daemon=True)
+    wthread.start()
+
+    import time
+    waited = {"reader": 0.0, "device": 0.0, "writer": 0.0}     # where this thread sat still (logged at the end)
 
     def flush(keep=0):
         nonlocal done
         while len(pending) > keep:
-            keys_p, host_p, ev = pending.pop(0)
+            keys_p, host_p, flags_p, ev = pending.pop(0)
+            t0 = time.perf_counter()
             ev.synchronize()
-            emb = trainer._checked(host_p.numpy())
-            if normalize:
-                emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
-            writer.write(keys_p, emb)
+            t1 = time.perf_counter()
+            if werr:
+                raise werr[0]
+            wq.put((keys_p, host_p, flags_p))           # blocks while the writer is a batch behind: its slots stay untouched
+            waited["device"] += t1 - t0
+            waited["writer"] += time.perf_counter() - t1
             done += len(keys_p)
 
+    with torch.cuda.device(dev_index):
+        comp = torch.cuda.current_stream(dev_index)
+        copy_s = torch.cuda.Stream(device=dev_index)
+        dev_in = [None] * NSLOT
+        emb_pins = [None] * NSLOT
+        flag_pins = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(NSLOT)]
+        slot_done = [None] * NSLOT
     turn = 0
-    while True:
-        b = q.get()
-        if b is end:
-            break
-        if isinstance(b, BaseException):
-            raise b
-        keys, offsets, feats = b
-        if frontend or np.diff(offsets).max() > chunk_size:
-            flush()                                     # these paths write synchronously: keep the output order
-        if frontend:
-            from .frontend import cmn_select_packed
-            vads = [vad_of(k) for k in keys] if vad_of else None
-            if vads is not None and any(v is None for v in vads):
-                missing = [k for k, v in zip(keys, vads) if v is None]
-                log.warning("[WARNING] no VAD decisions for %d utterance(s) (first: %s): skipped" % (len(missing), missing[0]))
-            with torch.cuda.device(dev_index):
-                raw = torch.from_numpy(feats).to("cuda:%d" % dev_index, non_blocking=True)
-                dev, offsets, kept = cmn_select_packed(raw, offsets, vads, cmn_window=cmn_window,
-                                                       min_frames=min_chunk_size)
-            extra_skipped += len(keys) - len(kept)
-            keys = [keys[i] for i in kept]
-            if not keys:
-                continue
-            if np.diff(offsets).max() > chunk_size:     # rare: finish on the host views of the processed batch
-                feats = dev.cpu().numpy()
-            else:
+    try:
+        while True:
+            t0 = time.perf_counter()
+            b = q.get()
+            waited["reader"] += time.perf_counter() - t0
+            if b is end:
+                break
+            if isinstance(b, BaseException):
+                raise b
+            keys, offsets, feats = b
+            lens_max = int(np.diff(offsets).max())
+            if frontend or lens_max > chunk_size:
+                flush()                                     # these paths write synchronously: keep the output order
+                _writer_idle(wq, werr)
+            if frontend:
+                from .frontend import cmn_select_packed
+                vads = [vad_of(k) for k in keys] if vad_of else None
+                if vads is not None and any(v is None for v in vads):
+                    missing = [k for k, v in zip(keys, vads) if v is None]
+                    log.warning("[WARNING] no VAD decisions for %d utterance(s) (first: %s): skipped" % (len(missing), missing[0]))
                 with torch.cuda.device(dev_index):
-                    emb = trainer._checked(trainer.predict_packed(dev, offsets).cpu().numpy())
-                if normalize:
-                    emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
-                writer.write(keys, emb)
-                done += len(keys)
+                    raw = torch.from_numpy(feats).to(devname, non_blocking=True)
+                    dev, offsets, kept = cmn_select_packed(raw, offsets, vads, cmn_window=cmn_window,
+                                                           min_frames=min_chunk_size)
+                extra_skipped += len(keys) - len(kept)
+                keys = [keys[i] for i in kept]
+                if not keys:
+                    continue
+                if np.diff(offsets).max() > chunk_size:     # rare: finish on the host views of the processed batch
+                    feats = dev.cpu().numpy()
+                else:
+                    with torch.cuda.device(dev_index):
+                        emb = trainer._checked(trainer.predict_packed(dev, offsets).cpu().numpy())
+                    if normalize:
+                        emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
+                    writer.write(keys, emb)
+                    done += len(keys)
+                    continue
+            lens = np.diff(offsets)
+            if lens.max() > chunk_size:                     # rare: chunk / weight / average on views
+                items = [(k, feats[offsets[i]:offsets[i + 1]]) for i, k in enumerate(keys)]
+                out = []
+                extract_stream(trainer.predict_list, iter(items), lambda k, v: out.append((k, v)), min_chunk_size,
+                               chunk_size, normalize, batch_frames, prefetch=0)
+                writer.write([k for k, _ in out], np.stack([v for _, v in out]))
+                done += len(out)
                 continue
-        lens = np.diff(offsets)
-        if lens.max() > chunk_size:                     # rare: chunk / weight / average on views
-            items = [(k, feats[offsets[i]:offsets[i + 1]]) for i, k in enumerate(keys)]
-            out = []
-            extract_stream(trainer.predict_list, iter(items), lambda k, v: out.append((k, v)), min_chunk_size,
-                           chunk_size, normalize, batch_frames, prefetch=0)
-            writer.write([k for k, _ in out], np.stack([v for _, v in out]))
-            done += len(out)
-            continue
-        host = torch.from_numpy(feats)                  # view of the pinned staging buffer
-        with torch.cuda.device(dev_index):
-            dev = host.to("cuda:%d" % dev_index, non_blocking=True)
-            out = trainer.predict_packed(dev, offsets)
-            flat = emb_pins[turn & 1]
-            if flat is None or flat.numel() < out.numel():
-                flat = emb_pins[turn & 1] = torch.empty(max(out.numel(), 4096 * out.shape[1]), dtype=torch.float32, pin_memory=True)
-            host_out = flat[:out.numel()].view(out.shape)
-            host_out.copy_(out, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-        turn += 1
-        pending.append((list(keys), host_out, ev))
-        flush(keep=1)                                   # write batch i - 1 while the device runs batch i
-    flush()
+            host = torch.from_numpy(feats)                  # view of the pinned staging buffer
+            k = turn % NSLOT
+            with torch.cuda.device(dev_index):
+                if dev_in[k] is None or dev_in[k].shape[0] < host.shape[0] or dev_in[k].shape[1] != host.shape[1]:
+                    dev_in[k] = torch.empty((max(int(host.shape[0] * 1.25), 4096), host.shape[1]), dtype=torch.float32, device=devname)
+                    copy_s.wait_stream(comp)                # the block may still be in use by work queued on the compute stream
+                elif slot_done[k] is not None:
+                    copy_s.wait_event(slot_done[k])         # the forward that last read this buffer has finished
+                with torch.cuda.stream(copy_s):
+                    dev_in[k][:host.shape[0]].copy_(host, non_blocking=True)
+                    h2d = torch.cuda.Event()
+                    h2d.record(copy_s)
+                comp.wait_event(h2d)
+                info = trainer.plan_info(offsets)
+                rows_o, cols_o = int(info["out_rows"]), int(info["out_cols"])
+                flat = emb_pins[k]
+                if flat is None or flat.numel() < rows_o * cols_o:
+                    flat = emb_pins[k] = torch.empty(max(rows_o * cols_o, 4096 * cols_o), dtype=torch.float32, pin_memory=True)
+                host_out = flat[:rows_o * cols_o].view(rows_o, cols_o)
+                if info["frame_level"]:
+                    host_out.copy_(trainer.predict_packed(dev_in[k][:host.shape[0]], offsets), non_blocking=True)
+                else:                                       # the last kernel writes the embeddings straight into the pinned slot
+                    trainer.predict_packed(dev_in[k][:host.shape[0]], offsets, out=host_out)
+                trainer.flags_async(flag_pins[k])
+                ev = torch.cuda.Event()
+                ev.record(comp)
+                slot_done[k] = ev
+            turn += 1
+            pending.append((list(keys), host_out, flag_pins[k], ev))
+            flush(keep=KEEP)                                # hand batch i - 2 to the writer while the device runs i - 1 and i
+        flush()
+    finally:
+        wq.put(None)
+        wthread.join()
+    if werr:
+        raise werr[0]
+    log.info("[INFO] driver loop: %d batches; waited %.3f s for the reader, %.3f s for the device, %.3f s for the writer"
+             % (turn, waited["reader"], waited["device"], waited["writer"]))
     skipped = reader.skipped + extra_skipped
     reader.close()
     return done, skipped
+
+
+def _writer_idle(wq, werr):
+    """Block until the writer thread has consumed everything queued so far (queue.join semantics via task counts)."""
+    wq.join()
+    if werr:
+        raise werr[0]
 
 
 def main(argv=None):

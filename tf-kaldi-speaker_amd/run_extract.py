@@ -60,7 +60,7 @@ def build_parser():
     p.add_argument("--gpus", type=str, default="", help="comma-separated device ids to use (default: all visible)")
     p.add_argument("--cmn-window", "--cmn_window", type=int, default=300, help="sliding CMN window of the front-end (0 = features are already normalised)")
     p.add_argument("--apply-vad", "--apply_vad", type=_bool, default=True, help="select voiced frames with $data/vad.scp")
-    p.add_argument("--batch-frames", "--batch_frames", type=int, default=76800)
+    p.add_argument("--batch-frames", "--batch_frames", type=int, default=153600)
     p.add_argument("--precision", type=str, default="")
     p.add_argument("--job-module", type=str, default="tf_kaldi_speaker_amd.extract", help=argparse.SUPPRESS)
     p.add_argument("nnetdir")
@@ -248,11 +248,36 @@ def combine_scp(out_dir, nj, keys):
     return n
 
 
+def _kfd_gpu_count():
+    """GPU agents of the KFD topology (sysfs: a node with SIMDs is a GPU), capped by HIP_/ROCR_VISIBLE_DEVICES -- without importing
+    torch or loading the HIP runtime: the launcher's own start-up is on every job's clock.  None when sysfs says nothing."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        n += 1
+        if n == 0:
+            return None
+    except (OSError, ValueError, IndexError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def visible_gpus(spec=""):
     if spec:
         return [int(x) for x in spec.split(",") if x.strip() != ""]
-    import torch
-    return list(range(torch.cuda.device_count()))        # counting devices does not initialise the GPU
+    n = _kfd_gpu_count()
+    if n is None:
+        import torch
+        n = torch.cuda.device_count()                      # counting devices does not initialise the GPU
+    return list(range(n))
 
 
 def main(argv=None):
@@ -266,6 +291,11 @@ def main(argv=None):
             print("No such file %s" % f)
             return 1
     os.makedirs(os.path.join(args.dir, "log"), exist_ok=True)
+    if args.stage <= 3:
+        # stages 2-3 run on a GPU through torch: its import (a second or more) happens on a side thread while the jobs extract;
+        # importing does not touch a device
+        import threading
+        threading.Thread(target=lambda: __import__("torch"), daemon=True).start()
     gpus = visible_gpus(args.gpus)
     if not gpus:
         print("run_extract_embeddings: no HIP device visible (the extraction path has no CPU fallback)")

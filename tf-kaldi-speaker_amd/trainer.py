@@ -90,6 +90,9 @@ class Trainer(object):
         self._step = None
         self._torch = None
         self._pinned = None
+        self._slots = None                            # pipelined host interface (submit_list / collect): staging slots
+        self._copy_stream = None
+        self._slot_turn = 0
 
     # ------------------------------------------------------------------ graph build
     def build(self, mode, noupdate_var_list=None):
@@ -307,7 +310,9 @@ class Trainer(object):
         ws = self._workspace(info.workspace_bytes + 256)
         if out is None:
             out = torch.empty((int(info.out_rows), int(info.out_cols)), dtype=torch.float32, device=feats_dev.device)
-        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+        # `out` may also be PINNED host memory (device-accessible): the last kernel then writes the embeddings straight into it and
+        # no copy sits between two forwards (a D2H copy on the compute stream is an engine switch: tools/pipeline_probe.py)
+        assert (out.is_cuda or out.is_pinned()) and out.dtype == torch.float32 and out.is_contiguous()
         stream = torch.cuda.current_stream(self._device_index).cuda_stream
         args = (self._h, plan, C.c_void_p(feats_dev.data_ptr()), int(feats_dev.shape[1]),
                 C.c_void_p(out.data_ptr()), out.numel(), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream))
@@ -438,7 +443,17 @@ class Trainer(object):
     def predict_list(self, utterances, node=None):
         """Ragged batch: a list of [T_i, d] matrices packed back to back and run as ONE launch
         sequence (what the reference does with one sess.run per utterance, extract.py:89).
-        Returns [n, E] for a segment-level node, a list of [T_i', E] for a frame-level node."""
+        Returns [n, E] for a segment-level node, a list of [T_i', E] for a frame-level node.
+        = collect(submit_list(...)); callers that can keep two batches in flight use the pair directly."""
+        return self.collect(self.submit_list(utterances, node))
+
+    NUM_SLOTS = 3
+
+    def submit_list(self, utterances, node=None):
+        """Enqueue one ragged batch and return a ticket for collect(); nothing here waits for the device.  The batch is
+        packed into a pinned staging slot, copied to the device on a COPY stream (so that the copy of batch i + 1 runs
+        beside the kernels of batch i), run on the current stream, and its result and range flags are copied into the
+        slot's pinned output, all in stream order.  At most NUM_SLOTS tickets may be outstanding (two keep the device busy)."""
         if not self.is_loaded:
             self._lazy_load()
         torch = self._torch
@@ -449,23 +464,73 @@ class Trainer(object):
             raise ValueError("features have %d columns, the network needs %d" % (d, self.dim))
         offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         total = int(offsets[-1])
+        devname = "cuda:%d" % self._device_index
         with torch.cuda.device(self._device_index):
-            # pack straight into a reusable pinned staging buffer (one copy), then one async H2D
-            pin = self._pinned
-            if pin is None or pin.shape[0] < total or pin.shape[1] != d:
-                pin = self._pinned = torch.empty((max(total, 4096), d), dtype=torch.float32, pin_memory=True)
-            stage = pin.numpy()
-            pos = 0
-            for u, t in zip(utterances, lens):
-                stage[pos:pos + t] = u
-                pos += t
-            dev = pin[:total].to("cuda:%d" % self._device_index, non_blocking=True)
-            out = self.predict_packed(dev, offsets, node)
-            _, info = self._plan(offsets, node)
-            emb = self._checked(out.cpu().numpy())      # synchronises: the staging buffer is free again
-        if node == "attention_weights" or not info.frame_level:
+            comp = torch.cuda.current_stream(self._device_index)
+            if self._slots is None:
+                self._slots = [dict(pin=None, dev=None, out=None, flags=torch.zeros(2, dtype=torch.int32).pin_memory(),
+                                    done=None, busy=False) for _ in range(self.NUM_SLOTS)]
+                self._copy_stream = torch.cuda.Stream(device=self._device_index)
+            sl = self._slots[self._slot_turn % self.NUM_SLOTS]
+            if sl["busy"]:
+                raise RuntimeError("submit_list: %d batches are already in flight; collect() one first" % self.NUM_SLOTS)
+            self._slot_turn += 1
+            if sl["pin"] is None or sl["pin"].shape[0] < total or sl["pin"].shape[1] != d:
+                rows = max(int(total * 1.25), 4096)
+                sl["pin"] = torch.empty((rows, d), dtype=torch.float32, pin_memory=True)
+                sl["dev"] = torch.empty((rows, d), dtype=torch.float32, device=devname)
+                self._copy_stream.wait_stream(comp)          # the block may still be in use by work queued on the compute stream
+            self._pack(utterances, lens, d, sl["pin"])
+            with torch.cuda.stream(self._copy_stream):
+                sl["dev"][:total].copy_(sl["pin"][:total], non_blocking=True)
+                h2d = torch.cuda.Event()
+                h2d.record(self._copy_stream)
+            comp.wait_event(h2d)
+            plan, info = self._plan(offsets, node)
+            n_out = int(info.out_rows) * int(info.out_cols)
+            if sl["out"] is None or sl["out"].numel() < n_out:
+                sl["out"] = torch.empty(max(n_out, 1 << 18), dtype=torch.float32, pin_memory=True)
+            host_out = sl["out"][:n_out].view(int(info.out_rows), int(info.out_cols))
+            if not info.frame_level and node != "attention_weights":
+                self.predict_packed(sl["dev"][:total], offsets, node, out=host_out)      # [B, E]: written into the pinned slot directly
+            else:
+                out = self.predict_packed(sl["dev"][:total], offsets, node)
+                host_out.copy_(out, non_blocking=True)
+            self.flags_async(sl["flags"])
+            sl["done"] = torch.cuda.Event()
+            sl["done"].record(comp)
+            sl["busy"] = True
+        return (sl, host_out, lens, int(offsets[-1]), node, bool(info.frame_level))
+
+    def _pack(self, utterances, lens, d, pin):
+        """The ragged batch, a list of separate [T_i, d] matrices, back to back into the pinned staging slot: natively with four
+        threads when every matrix is C-contiguous float32 (xv_pack_rows; 9 MB per 256 x 300 frames are ~1 ms on one core),
+        row by row otherwise."""
+        n = len(utterances)
+        if all(isinstance(u, np.ndarray) and u.dtype == np.float32 and u.flags.c_contiguous and u.shape[1] == d for u in utterances):
+            ptrs = np.fromiter((u.__array_interface__["data"][0] for u in utterances), dtype=np.uint64, count=n)
+            nbytes = np.asarray(lens, dtype=np.int64) * (4 * d)
+            got = self._lib.xv_pack_rows(C.c_void_p(ptrs.ctypes.data), C.c_void_p(nbytes.ctypes.data), n,
+                                         C.c_void_p(pin.data_ptr()), 4)
+            if got != int(nbytes.sum()):
+                raise RuntimeError("xv_pack_rows copied %d of %d bytes" % (got, int(nbytes.sum())))
+            return
+        stage = pin.numpy()
+        pos = 0
+        for u, t in zip(utterances, lens):
+            stage[pos:pos + t] = u
+            pos += t
+
+    def collect(self, ticket):
+        """Wait for a batch submitted with submit_list and return what predict_list returns."""
+        sl, host_out, lens, total, node, frame_level = ticket
+        sl["done"].synchronize()
+        sl["busy"] = False
+        emb = host_out.numpy().copy()                   # the slot is reused by the next submit
+        self.raise_on_flags(self.decode_flags(sl["flags"]), emb)
+        if node == "attention_weights" or not frame_level:
             return emb
-        ctx = (int(offsets[-1]) - emb.shape[0]) // len(lens)
+        ctx = (total - emb.shape[0]) // len(lens)
         res, pos = [], 0
         for t in lens:
             res.append(emb[pos:pos + t - ctx])
@@ -485,6 +550,8 @@ class Trainer(object):
                 self._h = None
         self._ws = None
         self._pinned = None
+        self._slots = None
+        self._copy_stream = None
         self.is_loaded = False
 
     def close(self):
