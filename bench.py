@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--c4-utts", type=int, default=8192, help="config 4: size of the fixed utterance set")
     ap.add_argument("--c4-steps", type=int, default=3, help="config 4: timed passes over the set")
     ap.add_argument("--c4-batch-frames", type=int, default=153600, help="config 4: frames per ragged device batch")
-    ap.add_argument("--cli-utts", type=int, default=65536, help="cli leg: utterances in the ark")
+    ap.add_argument("--cli-utts", type=int, default=131072, help="cli leg: utterances in the ark")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the timing barrier (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses device 0 (with --dist-backend gloo)")
@@ -471,14 +471,20 @@ def main():
             tr.predict_list(utts)                          # warm-up (staging slots, copy stream)
         n_e2e = max(8, args.steps)
         t1 = time.perf_counter()
-        tickets = []
+        tickets, t_sub, t_col = [], 0.0, 0.0
         for i in range(n_e2e):
+            t2 = time.perf_counter()
             tickets.append(tr.submit_list(utts))
+            t3 = time.perf_counter()
             if len(tickets) == 2:
                 tr.collect(tickets.pop(0))
+            t_sub += t3 - t2
+            t_col += time.perf_counter() - t3
         while tickets:
             tr.collect(tickets.pop(0))
         e2e_rate = n_e2e * args.batch / (time.perf_counter() - t1)
+        print("[bench] e2e pipelined: %.3f ms per batch (submit %.3f, collect %.3f)"
+              % ((time.perf_counter() - t1) / n_e2e * 1e3, t_sub / n_e2e * 1e3, t_col / n_e2e * 1e3), file=sys.stderr)
         calls = []
         for i in range(max(3, args.steps // 2)):
             t1 = time.perf_counter()

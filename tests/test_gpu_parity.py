@@ -198,6 +198,28 @@ def test_resnet18_full_width_xvector(precision):
     tr.close()
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+def test_resnet18_full_width_baseline_geometry(precision):
+    """config 5 at its BASELINE geometry: full width (13.5 M parameters), 40-dim x 300-frame utterances (B = 2; the float64 oracle
+    on one of them takes a few seconds), plus a 301-frame neighbour in the pack so that the utterance checked does not start the
+    grid.  Everything else about the ResNet is tested on short utterances; this is the shape the bench measures."""
+    import torch
+    from tf_kaldi_speaker_amd import synth
+    params = dict(synth.RESNET_PARAMS)
+    weights = synth.synth_resnet_weights(params, seed=0)
+    lens = [301, 300]
+    utts = synth.synth_features(2, lens, 40, seed=19)
+    tr, _ = _trainer(params, weights, 40, precision)
+    packed = torch.from_numpy(np.concatenate(utts, axis=0)).cuda()
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    got = tr.predict_packed(packed, offsets).cpu().numpy()
+    ref = ref_numpy.predict(utts[1], weights, params, 40)
+    err = _rel(got[1], ref)
+    _note("resnet_full_T300", precision, "tdnn6_dense", err)
+    assert err <= TOL, err
+    tr.close()
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_xvector_300_frames(stat_model, precision):
     """BASELINE config 2 shape (30-dim x 300 frames), small batch, tdnn6_dense."""

@@ -410,6 +410,11 @@ __global__ void f6v2_tail_reduce_kernel(GemmArgs p, int mt0, int S) {
   dst[5] = uint4{cl[0], cl[1], cl[2], cl[3]};
   dst[6] = uint4{ch[4], ch[5], sc2, 0u};
   dst[7] = uint4{cl[4], cl[5], sc2, 0u};
+  if (m == p.M - 1) {                      // eight zero rows behind the value's last row (store_wave_tile_n32_f6)
+    for (int k = 1; k <= 8; ++k)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) dst[(int64_t)k * (p.ldsb >> 2) + c] = uint4{0u, 0u, 0u, 0u};
+  }
 }
 
 #undef V2_GLD16

@@ -132,8 +132,18 @@ __device__ __forceinline__ void store_wave_tile_n32_f6(const GemmArgs& p, const 
       const bool zero = r < -1;
       r = zero ? -r - 2 : r;
       if (zero) v = z;
-      if (r >= 0 && blk_ok)
-        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)r * p.ldsb * 4 + (nbase >> 5) * 128 + rchunk * 16) = v;
+      if (r >= 0 && blk_ok) {
+        char* dst = reinterpret_cast<char*>(p.Ysb) + (int64_t)r * p.ldsb * 4 + (nbase >> 5) * 128 + rchunk * 16;
+        *reinterpret_cast<f32x4*>(dst) = v;
+        // Eight zero rows behind the last row of the value: the reader's zero-weight taps (tap >= its width in a group of four)
+        // still multiply rows m + w .. m + 7, and behind the last row that is whatever the workspace held -- an E8M0 scale byte
+        // of 255 there is a NaN, and NaN x 0 = NaN.  Written here by the lanes that store the last row (GEMM row M - 1 is the
+        // last valid frame of the last utterance) instead of a memset per layer and forward.
+        if (mbase + ps * ROWS + row == p.M - 1) {
+#pragma unroll
+          for (int k = 1; k <= 8; ++k) *reinterpret_cast<f32x4*>(dst + (int64_t)k * p.ldsb * 4) = z;
+        }
+      }
     }
     wave_lds_sync();
   }

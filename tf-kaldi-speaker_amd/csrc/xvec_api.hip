@@ -1770,9 +1770,11 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           }
           a.ysb_f6 = st.out_f6 ? 1 : 0;
           // taps w .. 7 of a scaled MFMA have zero weights but still read rows m + w .. m + 7: behind the last input row that is
-          // whatever the buffer held, and an E8M0 scale byte of 255 there is a NaN (NaN x 0 = NaN) -- keep eight rows defined
-          XV_HIP(h, hipMemsetAsync(const_cast<char*>(static_cast<const char*>(a.Xsb)) + st.rows_in * (int64_t)sb_ld(L.cin) * 4, 0,
-                                   (size_t)8 * sb_ld(L.cin) * 4, s));
+          // whatever the buffer held, and an E8M0 scale byte of 255 there is a NaN (NaN x 0 = NaN) -- eight rows are kept defined:
+          // by the producer's epilogue when it wrote this format itself, by a memset behind the conversion pass otherwise
+          if (!st.in_f6)
+            XV_HIP(h, hipMemsetAsync(const_cast<char*>(static_cast<const char*>(a.Xsb)) + st.rows_in * (int64_t)sb_ld(L.cin) * 4, 0,
+                                     (size_t)8 * sb_ld(L.cin) * 4, s));
           a.ldsbx = sb_ld(L.cin);
           a.Wfr = L.wf6m.p;
           a.Wx6 = L.wf6x.p;
