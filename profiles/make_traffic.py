@@ -20,8 +20,9 @@ PARTS = {
     "f16f6": [
         ("im2col_sb_kernel", 1228800, None, "tdnn1_conv"),                                           # feature rows -> SB rows (staging of L1)
         ("w14p2_kernel", 614400, None, "tdnn1_conv"),                                                # L1 on the f16 kernel, F6-output epilogue
-        ("gemm_f16f6_kernel<5>", 606208, None, "tdnn2_conv"),
-        ("gemm_f16f6_kernel<7>", 598016, None, "tdnn3_conv"),
+        ("gemm_f6v2_kernel<5", 655360, None, "tdnn2_conv"),                                          # whole tiles + K-split tail slices
+        ("gemm_f6v2_kernel<7", 655360, None, "tdnn3_conv"),
+        ("f6v2_tail_reduce_kernel", 32768, None, "tdnn2_conv"), ("f6v2_tail_reduce_kernel", 16384, None, "tdnn3_conv"),
         ("w1p3_kernel", 585728, None, "tdnn4_dense"), ("w1p3_kernel", 1757184, None, "tdnn5_dense"),
     ],
 }

@@ -1,7 +1,7 @@
 # Collect the round's evidence on the GPU box: bench lines (default bf16x3 + exact f32 + the other configs),
 # rocprofv3 kernel trace/stats of the same command, PMC passes (separate runs, kernel-trace only).
 # usage: bash tools/profile_round.sh <tag>    -> gpurun_out/<tag>/
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -18,16 +18,13 @@ python bench.py --network extended_tdnn --precision f16f6 --cpu-seconds 0 --no-e
 step resnet; python bench.py --network resnet_18 --batch 64 --dim 40 --cpu-seconds 4 --no-extra > $out/bench_resnet18_bf16x3.json 2> $out/bench_resnet.err
 step f16; python bench.py --precision f16x3 --cpu-seconds 0 --no-extra > $out/bench_f16x3.json 2> $out/bench_f16x3.err
 step att_f16; python bench.py --pooling self_attention --precision f16x3 --cpu-seconds 0 --no-extra > $out/bench_att_f16x3.json 2> $out/bench_att_f16.err
-step ab; for n in tdnn att resnet; do python tools/ab_options.py slab3 $n 2>&1 | grep -v amdgpu.ids; done > $out/ab_slab3.txt 2>&1
-python tools/ab_options.py att_fusion att 2>&1 | grep -v amdgpu.ids > $out/ab_att_fusion.txt 2>&1
-python tools/ab_options.py pool_fusion tdnn 2>&1 | grep -v amdgpu.ids > $out/ab_pool_fusion.txt 2>&1
-python tools/ab_options.py tail_split tdnn 2>&1 | grep -v amdgpu.ids > $out/ab_tail_split.txt 2>&1
-python tools/ab_options.py grid_compact resnet 2>&1 | grep -v amdgpu.ids > $out/ab_grid_compact.txt 2>&1
+step ab; python tools/ab_options.py tail_split tdnn 2>&1 | grep -v amdgpu.ids > $out/ab_tail_split.txt 2>&1
 python tools/reader_rate.py 100000 /tmp 2>&1 | grep -v amdgpu.ids > $out/reader_rate.txt
-for n in tdnn att resnet; do python tools/two_streams.py $n 2 2>&1 | grep -v amdgpu.ids | tail -2; done > $out/two_streams.txt 2>&1
-step cli; python tools/cli_throughput.py 100000 2>&1 | grep -v amdgpu.ids > $out/cli_throughput.txt; python tools/cli_throughput.py 300000 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt; python tools/cli_throughput.py 50000 --varlen 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt; python tools/cli_throughput.py 150000 --varlen 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt
+for p in f16f6 bf16x3; do python tools/layer_times.py tdnn $p 2>&1 | grep -v amdgpu.ids | tail -2; done > $out/layer_times.txt 2>&1
+step cli; python tools/cli_throughput.py 100000 2>&1 | grep -v amdgpu.ids > $out/cli_throughput.txt; python tools/cli_throughput.py 300000 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt; python tools/cli_throughput.py 150000 --varlen 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt
+step host; python tools/host_profile.py 100000 2>&1 | grep -v amdgpu.ids > $out/host_profile.txt; python tools/pipeline_probe.py 2>&1 | grep -v amdgpu.ids > $out/pipeline_probe.txt
 step trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --cpu-seconds 0 --no-extra > $out/trace.log 2>&1
-step pmc_sq; timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -- python bench.py --cpu-seconds 0 --no-extra --steps 3 --warmup 1 --no-profile > $out/pmc_sq.log 2>&1
+step pmc_sq; timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -- python bench.py --cpu-seconds 0 --no-extra --steps 3 --warmup 1 --no-profile > $out/pmc_sq.log 2>&1
 step pmc_fetch; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py --cpu-seconds 0 --no-extra --steps 3 --warmup 1 --no-profile > $out/pmc_fetch.log 2>&1
 step pmc_write; timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py --cpu-seconds 0 --no-extra --steps 3 --warmup 1 --no-profile > $out/pmc_write.log 2>&1
 step trace_att; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_att -- python bench.py --pooling self_attention --cpu-seconds 0 --no-extra > $out/trace_att.log 2>&1
