@@ -432,15 +432,10 @@ __global__ void im2col_sb_kernel(const float* __restrict__ x, int64_t ldx, int c
   // reduce the words, and the host refuses a batch whose features all sit below 2^-8, where the low halves are subnormal and even
   // the largest value keeps fewer than 17 bits.
   if (f16 && ovf) {
-    __shared__ float wmax[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-      reinterpret_cast<float*>(ovf + kFlagWords)[blockIdx.x] = (m <= 3.0e38f) ? m : 0.f;
-    }
+    if ((threadIdx.x & 63) == 0)           // one word per wave: no barrier, no atomic
+      reinterpret_cast<float*>(ovf + kFlagWords)[blockIdx.x * 4 + (threadIdx.x >> 6)] = (mx <= 3.0e38f) ? mx : 0.f;
   }
 }
 
@@ -448,7 +443,7 @@ hipError_t launch_im2col_sb(const float* x, int64_t ldx, int cin, int w, int64_t
                             int* ovf, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   const int64_t total = rows * (ldsb >> 1);
-  const int blocks = (int)((total + 255) / 256 > kFeatMaxSlots ? kFeatMaxSlots : (total + 255) / 256);
+  const int blocks = (int)((total + 255) / 256 > kFeatMaxSlots / 4 ? kFeatMaxSlots / 4 : (total + 255) / 256);
   hipLaunchKernelGGL(im2col_sb_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, cin, w * cin, rows,
                      static_cast<char*>(out_sb), ldsb, f16, ovf);
   return hipGetLastError();
@@ -505,15 +500,19 @@ hipError_t launch_l2_scale(const float* x, int64_t rows, int C, float factor, fl
 // memset are two engine switches between two forwards: together with the result copy they cost 0.15 ms of device time per 1.27 ms
 // batch -- tools/pipeline_probe.py.)
 __global__ void flags_snapshot_kernel(int* __restrict__ dev, int* __restrict__ host) {
-  float* part = reinterpret_cast<float*>(dev + kFlagWords);          // per-workgroup feature maxima of the staging kernel
+  float* part = reinterpret_cast<float*>(dev + kFlagWords);          // per-wave feature maxima of the staging kernel
+  __shared__ float wmax[16];
   float mx = 0.f;
-  for (int i = threadIdx.x; i < kFeatMaxSlots; i += 64) {
+  for (int i = threadIdx.x; i < kFeatMaxSlots; i += 1024) {
     mx = fmaxf(mx, part[i]);
     part[i] = 0.f;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
   if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, wmax[i]);
     host[0] = dev[0];
     host[1] = __float_as_int(fmaxf(mx, __int_as_float(dev[1])));
     dev[0] = 0;
@@ -523,7 +522,7 @@ __global__ void flags_snapshot_kernel(int* __restrict__ dev, int* __restrict__ h
 }
 
 hipError_t launch_flags_snapshot(int* dev, int* host, hipStream_t s) {
-  hipLaunchKernelGGL(flags_snapshot_kernel, dim3(1), dim3(64), 0, s, dev, host);
+  hipLaunchKernelGGL(flags_snapshot_kernel, dim3(1), dim3(1024), 0, s, dev, host);
   return hipGetLastError();
 }
 

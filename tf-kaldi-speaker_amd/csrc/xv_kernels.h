@@ -11,8 +11,8 @@ enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_PRELU = 3, ACT_T
 
 constexpr float kLreluAlpha = 0.2f;       // tf.nn.leaky_relu default (model/tdnn.py:33)
 // fp16 range guard buffer of a handle: kFlagWords ints ([0] overflow flag, [1] bits of a feature maximum carried over), then
-// kFeatMaxSlots floats: the largest feature magnitude each workgroup of the feature staging kernel saw since the last read-out
-constexpr int kFlagWords = 4, kFeatMaxSlots = 8192;
+// kFeatMaxSlots floats: the largest feature magnitude each wave of the feature staging kernel saw since the last read-out
+constexpr int kFlagWords = 4, kFeatMaxSlots = 32768;      // 8192 workgroups x 4 waves
 constexpr float kVarFloor = 1e-12f;       // VAR2STD_EPSILON (model/pooling.py:6)
 
 // One "overlapping-row" GEMM:  Y[rowmap[m], n] = act((sum_k A[m,k] * Wt[n,k]) * scale[n] + shift[n])
