@@ -235,12 +235,13 @@ def test_compact_grid_rows_are_bit_identical_to_the_full_enumeration(kw):
 
 @pytest.mark.parametrize("net", ["tdnn", "tdnn_narrow", "etdnn"])
 def test_f16f6_two_unit_split(net):
-    """XV_PREC_F16F6: the 5- and 7-tap convolutions compute hi*hi in fp16 and the two cross terms on the block-scaled fp6 path
-    (csrc/gemm_f16f6.hip: 1.5 MFMA units per product instead of 3).  tests/analysis/f16f8_error_model.py predicts ~1e-5 on the x-vector;
+    """XV_PREC_F16F6: the 5-, 7- and 9-tap convolutions compute hi*hi in fp16 and the two cross terms on the block-scaled fp6 path
+    (csrc/gemm_f6v2.hip: 1.5 MFMA units per product instead of 3).  tests/analysis/f16f8_error_model.py predicts ~1e-5 on the x-vector;
     the bar is the path's 1e-4 against the float64 oracle, on every stage endpoint of the converted layers (their conv / bn
     stages run through the same kernel with other epilogue vectors) and on the embedding; against the exact fp32 path the
     frame-level layers must stay within 5e-5.  Ragged batch with the shortest possible utterance; narrow variant: 64 channels
-    (two channel blocks, N below the tile); extended TDNN: its 9-tap layer is not eligible and stays on f16x3.  Deterministic."""
+    (two channel blocks, N below the tile); extended TDNN: 5-, 5-, 7- and 9-tap layers (three macro steps of four taps in the last one,
+    behind a one-tap dense layer whose split-blocked output goes through the conversion pass).  Deterministic."""
     from oracle import ref_numpy
     from tf_kaldi_speaker_amd import synth
     import torch
@@ -254,11 +255,11 @@ def test_f16f6_two_unit_split(net):
     feats = torch.from_numpy(np.concatenate(utts)).cuda()
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     emb = params["embedding_node"]
-    nodes = ("tdnn3_conv", "tdnn3_bn", "tdnn3_relu", "tdnn5_relu", emb) if net == "etdnn" else \
+    nodes = ("tdnn3_conv", "tdnn3_bn", "tdnn3_relu", "tdnn5_relu", "tdnn7_conv", "tdnn7_relu", emb) if net == "etdnn" else \
             ("tdnn2_conv", "tdnn2_bn", "tdnn2_relu", "tdnn3_relu", emb)
     tr = _trainer(params, weights, 30, "f16f6")
     got = _run_nodes(tr, feats, offs, nodes)            # _run_nodes also checks bit-identical repetition
-    # the zero-weight taps of a scaled MFMA read up to seven rows behind the last input row: with the workspace full of 0xFF
+    # the zero-weight taps of a scaled MFMA read up to eleven rows behind the last input row: with the workspace full of 0xFF
     # (an E8M0 scale byte of 255 is a NaN, and NaN x 0 = NaN) the result must not change
     tr._ws.fill_(255)
     again = tr.predict_packed(feats, offs, emb).cpu().numpy().astype(np.float64)

@@ -412,7 +412,7 @@ __device__ __forceinline__ void tile_of_block(int id, int nMt, int nNt, int& mt,
 }
 
 template <int NPS, int EPI = 0, bool F16 = false>
-__device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, int w, char* smem3, int cb_begin, int cb_end) {
+__device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, int w, char* smem3, int cb_begin, int cb_end, bool slice = false) {
   char* As = smem3;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -561,8 +561,21 @@ __device__ __forceinline__ void w14p2_tile(const GemmArgs& p, int m0, int n0, in
   // loop, where they would cost registers (and spill) for its whole duration
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
-  if constexpr (EPI == 3) store_wave_tile_n32_f6(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);      // XV_PREC_F16F6 producer
-  else if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
+  if constexpr (EPI == 3) {                // XV_PREC_F16F6 producer: the two-unit block format
+    if (slice) {
+      // K-split slice of a tail tile: the raw accumulators go to the slice's rows of GemmArgs::partial (p.Y / p.ldy were pointed
+      // there by the kernel), 16-byte stores straight from the accumulator layout as in gemm_f6v2.hip -- a second LDS epilogue in
+      // this instantiation would not fit its registers
+      const int c16e = lane_e & 15, g4e = lane_e >> 4;
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          *reinterpret_cast<f32x4*>(p.Y + (int64_t)(m0 + 16 * g + c16e) * p.ldy + n0 + wave * 32 + 16 * c + 4 * g4e) = acc[g][c];
+      return;
+    }
+    store_wave_tile_n32_f6(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
+  } else if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
   else store_wave_tile_n32<64, F16>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
   stamp(3);
 }
@@ -762,7 +775,8 @@ __device__ __forceinline__ void w1p3_tile(const GemmArgs& p, int m0, int n0, cha
   // loop, where they would cost registers (and spill) for its whole duration
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
-  if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
+  if constexpr (EPI == 3) store_wave_tile_n32_f6(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);      // XV_PREC_F16F6 producer
+  else if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem3);
   else store_wave_tile_n32<64, F16>(p, acc, m0, n0 + wv * 32, lane_e, wave, smem3);
   stamp(3);
 }
@@ -785,7 +799,19 @@ template <int NPS, int EPI = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_kernel(GemmArgs p, int nMt, int nNt, int w, int S) {
   extern __shared__ __attribute__((aligned(16))) char smem3[];
   int mt, nt, cb_begin = 0, cb_end = (p.Kpad >> 5) / w;
-  if (EPI == 0 && (int)blockIdx.x >= nMt * nNt) {
+  bool slice = false;
+  if (EPI == 3 && (int)blockIdx.x >= nMt * nNt) {
+    const int id = blockIdx.x - nMt * nNt;
+    const int split = id % S, tile = id / S;
+    mt = nMt + tile / nNt;
+    nt = tile % nNt;
+    const int per = cb_end / S;
+    cb_begin = split * per;
+    cb_end = cb_begin + per;
+    p.Y = p.partial + ((int64_t)split * p.tail_mt - nMt) * (int64_t)BM * p.Npad;
+    p.ldy = p.Npad;
+    slice = true;
+  } else if (EPI == 0 && (int)blockIdx.x >= nMt * nNt) {
     const int id = blockIdx.x - nMt * nNt;
     const int split = id % S, tile = id / S;
     mt = nMt + tile / nNt;
@@ -807,7 +833,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_w14p2_kernel(GemmArgs p, i
   } else {
     tile_of_block(blockIdx.x, nMt, nNt, mt, nt);
   }
-  w14p2_tile<NPS, EPI, F16>(p, mt * BM, nt * BN, w, smem3, cb_begin, cb_end);
+  w14p2_tile<NPS, EPI, F16>(p, mt * BM, nt * BN, w, smem3, cb_begin, cb_end, slice);
 }
 
 // one thread per (tail row, 4 channels): ordered sum of the K slices, then the usual epilogue (BN scale/shift,
@@ -916,7 +942,7 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
           reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 1, false>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 2, false>),
           reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1, 0, true>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 0, true>),
           reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 1, true>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 2, true>),
-          reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1, 3, true>)};
+          reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<1, 3, true>), reinterpret_cast<const void*>(gemm_bf16x3_w14p2_kernel<4, 3, true>)};
       hipError_t r = hipSuccess;
       for (const void* k : kernels) {
         r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw32);
@@ -926,7 +952,8 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
           reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, false>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, true>),
           reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<1, false>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<1, true>),
           reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<2, false>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<2, true>),
-          reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, false, true>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, true, true>)};
+          reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, false, true>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, true, true>),
+          reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<3, true>)};
       for (const void* k : kernels3) {
         r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw1p3);
         if (r != hipSuccess) return r;
@@ -998,8 +1025,10 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
     else       hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, false, true>), grid, block, smemw1p3, s, a, nMain, nNt);
     return hipGetLastError();
   }
+  if (a.ysb_f6 && (!a.f16 || (w > 1 && w < 5) || !a.Ysb || a.Y || a.R || a.pool_part)) return hipErrorInvalidValue;
   if (w == 1 && !tail && a.slab3) {             // one tap: three slab buffers, slabs two steps ahead
-    if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, true>), grid, block, smemw1p3, s, a, nMain, nNt);
+    if (a.ysb_f6) hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<3, true>), grid, block, smemw1p3, s, a, nMain, nNt);
+    else if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, true>), grid, block, smemw1p3, s, a, nMain, nNt);
     else       hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, false>), grid, block, smemw1p3, s, a, nMain, nNt);
     return hipGetLastError();
   }
@@ -1007,9 +1036,12 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
   const int S = tail ? a.ksplit : 0;
   const dim3 grid2(nMain * nNt + (tail ? a.tail_mt * nNt * a.ksplit : 0));
   if (a.ysb_f6) {                               // XV_PREC_F16F6: this layer's only reader is a two-unit layer -> its block format
-    if (!a.f16 || w < 5 || tail || !a.Ysb || a.Y || a.R || a.pool_part) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 3, true>), grid2, block, smemw32, s, a, nMain, nNt, w, 0);
-    return hipGetLastError();
+    // (whole tiles through the block-format epilogue, the K-split slices as raw sums that the two-unit kernel's reduce finishes)
+    if (w >= 5) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 3, true>), grid2, block, smemw32, s, a, nMain, nNt, w, S);
+    else        hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<4, 3, true>), grid2, block, smemw32, s, a, nMain, nNt, w, S);
+    const hipError_t e6 = hipGetLastError();
+    if (e6 != hipSuccess || !tail) return e6;
+    return launch_f6v2_tail_reduce(a, nMain, s);
   }
   if (w >= 5) {
     if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w14p2_kernel<1, 0, true>), grid2, block, smemw32, s, a, nMain, nNt, w, S);

@@ -37,7 +37,11 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lptr2_t;
 
-constexpr int V2_BM = 128, V2_BN = 128, V2_DROW = 128, V2_DA_ROWS = 136, V2_DA_BYTES = V2_DA_ROWS * V2_DROW;
+constexpr int V2_BM = 128, V2_BN = 128, V2_DROW = 128;
+// slab rows: 128 frames + the halo of the last tap group (a group of four taps reads up to row 15 + 4 q + 3 of the last tile), in
+// whole 8-row DMA pieces: 136 rows for two macro steps (5 / 7 taps), 144 for three (9 taps)
+constexpr int v2_groups(int ntaps) { return ntaps <= 8 ? 17 : 18; }
+constexpr int v2_slab_bytes(int ntaps) { return v2_groups(ntaps) * 8 * V2_DROW; }
 constexpr int64_t kMainCt = 64 * 16;               // bytes per (tap, 16-channel tile) of the main weights: 64 lanes x 16 B
 constexpr int64_t kXCt = 2 * 64 * 16;              // per (macro step, term, 16-channel tile) of the cross weights: 64 x 16 B codes 0-15 |
                                                    // 64 x 16 B {codes 16-23, scale dword, pad}: one lane offset serves both planes
@@ -56,7 +60,9 @@ struct WSet { f16x8 w[2][2]; };                    // [tap of the pair][channel 
 
 template <int NTAPS, bool OUT_F6>
 __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, char* smem, int cb_begin, int cb_end, bool slice) {
-  static_assert(NTAPS == 5 || NTAPS == 7, "taps");
+  static_assert(NTAPS == 5 || NTAPS == 7 || NTAPS == 9, "taps");
+  constexpr int NQ = (NTAPS + 3) / 4;    // macro steps (groups of four taps) per channel block
+  constexpr int NGRP = v2_groups(NTAPS), V2_DA_BYTES = v2_slab_bytes(NTAPS);
   constexpr int NSLOT = 2;               // fragment slots per phase: tile g + 1 is read while tile g multiplies
   const int tid = threadIdx.x;
   int lane = tid & 63;
@@ -98,27 +104,27 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int g = wave + 4 * i;
-      dma_a(nx, (cb + 1) & 1, g < 17 ? g : 16, l);
+      dma_a(nx, (cb + 1) & 1, g < NGRP ? g : NGRP - 1, l);
     }
   };
   // weights of this wave's 32-channel block: uniform bases (scalar registers) + one lane offset each
   const int nb = (n0 >> 5) + wave;
-  const char* Wm = reinterpret_cast<const char*>(p.Wfr) + (int64_t)nb * ncb * 16 * kMainCt;       // [cb][8 taps][2 tiles][1 KB]
-  const char* Wx = reinterpret_cast<const char*>(p.Wx6) + (int64_t)nb * ncb * 8 * kXCt;           // [cb][q][term][2 tiles][1792 B]
+  const char* Wm = reinterpret_cast<const char*>(p.Wfr) + (int64_t)nb * ncb * (8 * NQ) * kMainCt;     // [cb][4 NQ taps][2 tiles][1 KB]
+  const char* Wx = reinterpret_cast<const char*>(p.Wx6) + (int64_t)nb * ncb * (4 * NQ) * kXCt;        // [cb][q][term][2 tiles][2 KB]
   auto load_w2 = [&](WSet& W, int cb, int tap0) __attribute__((always_inline)) {
     const int voA = lane_now() << 4;
-    const char* b = Wm + ((int64_t)cb * 16 + tap0 * 2) * kMainCt;
+    const char* b = Wm + ((int64_t)cb * (8 * NQ) + tap0 * 2) * kMainCt;
     V2_GLD16(W.w[0][0], voA, b, 0); V2_GLD16(W.w[0][1], voA, b, 1024);
     V2_GLD16(W.w[1][0], voA, b, 2048); V2_GLD16(W.w[1][1], voA, b, 3072);
   };
   auto load_w1 = [&](WSet& W, int cb, int tap0) __attribute__((always_inline)) {
     const int voA = lane_now() << 4;
-    const char* b = Wm + ((int64_t)cb * 16 + tap0 * 2) * kMainCt;
+    const char* b = Wm + ((int64_t)cb * (8 * NQ) + tap0 * 2) * kMainCt;
     V2_GLD16(W.w[0][0], voA, b, 0); V2_GLD16(W.w[0][1], voA, b, 1024);
   };
   auto load_x = [&](XSet& X, int cb, int q, int term) __attribute__((always_inline)) {
     const int voA = lane_now() << 4;
-    const char* b = Wx + ((((int64_t)cb * 2 + q) * 2 + term) * 2) * kXCt;
+    const char* b = Wx + ((((int64_t)cb * NQ + q) * 2 + term) * 2) * kXCt;
     V2_GLD16(X.c[0], voA, b, 0); V2_GLD16(X.t[0], voA, b, 1024);
     V2_GLD16(X.c[1], voA, b, 2048); V2_GLD16(X.t[1], voA, b, 3072);
   };
@@ -200,11 +206,11 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   XSet XA, XB;
   WSet WA, WB;
   // prologue: slab cb_begin; XA, XB = the cross sets of (cb_begin, q 0); 7 taps: WA = taps 0, 1; 5 taps: WB = taps 2, 3
-  for (int g = wave; g < 17; g += 4) dma_a(cb_begin, cb_begin & 1, g, lane_now());
+  for (int g = wave; g < NGRP; g += 4) dma_a(cb_begin, cb_begin & 1, g, lane_now());
   load_x(XA, cb_begin, 0, 0);
   load_x(XB, cb_begin, 0, 1);
   if (NTAPS == 7) load_w2(WA, cb_begin, 0);
-  else load_w2(WB, cb_begin, 2);
+  else load_w2(WB, cb_begin, 2);           // (5 and 9 taps issue WA = taps 0, 1 at the top of the channel block)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -251,6 +257,53 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
       if constexpr (!last) { V2_WAITW1(8, WB); load_w2(WA, nx, 0); } else { V2_WAITW1(0, WB); }
       __builtin_amdgcn_sched_barrier(0);
       m_phase(WB, cb, 6, 1);
+    } else if constexpr (NTAPS == 9) {
+      //   9 taps  XA0: WA(0,1) x4, slab x5 | XB0: XA(q1) x4 | M01: XB(q1) x4 | M23: WA(4,5) x4 | XA1: WB(6,7) x4 | XB1: XA(q2) x4 | M45: XB(q2) x4 |
+      //           M67: WA(8) x2 | XA2: WB(2,3)' x4 | XB2: XA(q0') x4 | M8: XB(q0') x4
+      //   waits   XA0 4   XB0 9 (4)   M01 9 (4)   M23 8   XA1 8   XB1 8   M45 8   M67 8   XA2 6   XB2 6 (2)   M8 8 (0)
+      V2_WAITX(4, XA);
+      load_w2(WA, cb, 0);
+      if constexpr (!last) dma_next(cb);
+      __builtin_amdgcn_sched_barrier(0);
+      x_phase(XA, cb, 0, 0);
+      if constexpr (!last) V2_WAITX(9, XB); else V2_WAITX(4, XB);
+      load_x(XA, cb, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      x_phase(XB, cb, 0, 1);
+      if constexpr (!last) V2_WAITW2(9, WA); else V2_WAITW2(4, WA);
+      load_x(XB, cb, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      m_phase(WA, cb, 0, 2);
+      V2_WAITW2(8, WB);
+      load_w2(WA, cb, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      m_phase(WB, cb, 2, 2);
+      V2_WAITX(8, XA);
+      load_w2(WB, cb, 6);
+      __builtin_amdgcn_sched_barrier(0);
+      x_phase(XA, cb, 1, 0);
+      V2_WAITX(8, XB);
+      load_x(XA, cb, 2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      x_phase(XB, cb, 1, 1);
+      V2_WAITW2(8, WA);
+      load_x(XB, cb, 2, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      m_phase(WA, cb, 4, 2);
+      V2_WAITW2(8, WB);
+      load_w1(WA, cb, 8);
+      __builtin_amdgcn_sched_barrier(0);
+      m_phase(WB, cb, 6, 2);
+      V2_WAITX(6, XA);
+      if constexpr (!last) load_w2(WB, nx, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      x_phase(XA, cb, 2, 0);
+      if constexpr (!last) { V2_WAITX(6, XB); load_x(XA, nx, 0, 0); } else { V2_WAITX(2, XB); }
+      __builtin_amdgcn_sched_barrier(0);
+      x_phase(XB, cb, 2, 1);
+      if constexpr (!last) { V2_WAITW1(8, WA); load_x(XB, nx, 0, 1); } else { V2_WAITW1(0, WA); }
+      __builtin_amdgcn_sched_barrier(0);
+      m_phase(WA, cb, 8, 1);
     } else {
       V2_WAITX(4, XA);
       load_w2(WA, cb, 0);                 // (the one set with a single macro step of lead: its registers serve tap 4 until the end of
@@ -429,27 +482,27 @@ __global__ __launch_bounds__(64) void f6v2_tail_reduce_kernel(GemmArgs p, int mt
 #undef V2_WAITW1
 
 // a.Xsb = activations in the two-unit block format (row stride a.ldsbx channels), a.Wfr / a.Wx6 = main / cross weights
-// (xvec_api.hip, upload_layer), a.K = taps * a.cin, taps 5 or 7, a.cin % 32 == 0.  a.tail_mt / a.ksplit / a.partial: the K-split tail
+// (xvec_api.hip, upload_layer), a.K = taps * a.cin, taps 5, 7 or 9, a.cin % 32 == 0.  a.tail_mt / a.ksplit / a.partial: the K-split tail
 // (gemm_bf16x3_tail_plan), decided at plan time.
 hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   const int taps = a.cin > 0 ? a.K / a.cin : 0;
-  // Only the widths the reference's graphs contain are instantiated (tdnn: 5, 5, 7; extended tdnn: 5, 5, 7 and a 9-tap layer that
-  // stays on the three-unit kernel).
-  if ((taps != 5 && taps != 7) || (a.cin & 31) || a.ldsbx != a.cin || !a.Wx6 || !a.Wfr || a.a_pitch || a.pool_part || a.R || (a.N & 3))
+  // Only the widths the reference's graphs contain are instantiated (tdnn: 5, 5, 7; extended tdnn: 5, 5, 7, 9).
+  if ((taps != 5 && taps != 7 && taps != 9) || (a.cin & 31) || a.ldsbx != a.cin || !a.Wx6 || !a.Wfr || a.a_pitch || a.pool_part || a.R || (a.N & 3))
     return hipErrorInvalidValue;
   static std::mutex mu;
   static bool attr_set[64] = {};
-  const size_t smem = (size_t)2 * V2_DA_BYTES;
+  const size_t smem = (size_t)2 * v2_slab_bytes(taps);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   {
     std::lock_guard<std::mutex> lock(mu);
     if (!attr_set[dev & 63]) {
       const void* ks[] = {reinterpret_cast<const void*>(gemm_f6v2_kernel<5, false>), reinterpret_cast<const void*>(gemm_f6v2_kernel<7, false>),
-                          reinterpret_cast<const void*>(gemm_f6v2_kernel<5, true>), reinterpret_cast<const void*>(gemm_f6v2_kernel<7, true>)};
+                          reinterpret_cast<const void*>(gemm_f6v2_kernel<5, true>), reinterpret_cast<const void*>(gemm_f6v2_kernel<7, true>),
+                          reinterpret_cast<const void*>(gemm_f6v2_kernel<9, false>), reinterpret_cast<const void*>(gemm_f6v2_kernel<9, true>)};
       for (const void* k : ks) {
-        const hipError_t r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        const hipError_t r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * v2_slab_bytes(9));
         if (r != hipSuccess) return r;
       }
       attr_set[dev & 63] = true;
@@ -465,12 +518,21 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
   if (taps == 5) {
     if (out_f6) hipLaunchKernelGGL((gemm_f6v2_kernel<5, true>), grid, block, smem, s, a, nMain, nNt, S);
     else        hipLaunchKernelGGL((gemm_f6v2_kernel<5, false>), grid, block, smem, s, a, nMain, nNt, S);
-  } else {
+  } else if (taps == 7) {
     if (out_f6) hipLaunchKernelGGL((gemm_f6v2_kernel<7, true>), grid, block, smem, s, a, nMain, nNt, S);
     else        hipLaunchKernelGGL((gemm_f6v2_kernel<7, false>), grid, block, smem, s, a, nMain, nNt, S);
+  } else {
+    if (out_f6) hipLaunchKernelGGL((gemm_f6v2_kernel<9, true>), grid, block, smem, s, a, nMain, nNt, S);
+    else        hipLaunchKernelGGL((gemm_f6v2_kernel<9, false>), grid, block, smem, s, a, nMain, nNt, S);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || !tail) return e;
+  return launch_f6v2_tail_reduce(a, nMain, s);
+}
+
+// The reduce of a K-split tail (rows from M tile nMain on; a.partial, a.tail_mt, a.ksplit as planned) with the split-blocked or the
+// two-unit block output; also the tail of a one-tap or f16 multi-tap layer that writes the block format (gemm_bf16x3.hip).
+hipError_t launch_f6v2_tail_reduce(const GemmArgs& a, int nMain, hipStream_t s) {
   const int64_t total = (int64_t)a.tail_mt * V2_BM * (a.Npad >> 5);
   const dim3 rgrid((unsigned)((total + 63) / 64)), rblock(64);
   switch (a.ksplit) {

@@ -801,17 +801,18 @@ int upload_layer(xv_handle* h, Layer& L) {
     XV_HIP(h, L.wfr.alloc(elems * 4));
     XV_HIP(h, hipMemcpy(L.wfr.p, fr.data(), elems * 4, hipMemcpyHostToDevice));
     if (L.use_f6) {
-      // gemm_f6v2_kernel operands (the scaled weights w * wscale, like the f16 halves above): taps padded to 8 with zeros.
-      //   main  [Npad/32][cin/32][8 taps][2 channel tiles][64 lanes = 16 * k-chunk + channel][8 x f16]
-      //   cross [Npad/32][cin/32][2 macro steps][2 terms: q6(w - f16(w)), q6(f16(w))][2 channel tiles] x { 64 x 16 B codes 0-15 |
+      // gemm_f6v2_kernel operands (the scaled weights w * wscale, like the f16 halves above): taps padded with zeros to NQ groups of
+      // four (NQ = 2 for 5 / 7 taps, 3 for 9).
+      //   main  [Npad/32][cin/32][4 NQ taps][2 channel tiles][64 lanes = 16 * k-chunk + channel][8 x f16]
+      //   cross [Npad/32][cin/32][NQ macro steps][2 terms: q6(w - f16(w)), q6(f16(w))][2 channel tiles] x { 64 x 16 B codes 0-15 |
       //         64 x 16 B {codes 16-23, scale dword (E8M0 in byte 0), pad} },  lane = 16 * (tap & 3) + channel: K group = tap inside the macro step
-      const int ncb = L.cin / 32;
+      const int ncb = L.cin / 32, NQ = (L.w + 3) / 4;
       const size_t main_ct = 64 * 16, cross_ct = 2 * 64 * 16;
-      std::vector<unsigned char> wm((size_t)(L.Npad / 32) * ncb * 8 * 2 * main_ct, 0), wx((size_t)(L.Npad / 32) * ncb * 2 * 2 * 2 * cross_ct, 0);
+      std::vector<unsigned char> wm((size_t)(L.Npad / 32) * ncb * (4 * NQ) * 2 * main_ct, 0), wx((size_t)(L.Npad / 32) * ncb * NQ * 2 * 2 * cross_ct, 0);
       for (int n = 0; n < L.Npad; ++n) {
         const int nb = n >> 5, ct = (n >> 4) & 1, r16 = n & 15;
         for (int cb = 0; cb < ncb; ++cb)
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 0; j < 4 * NQ; ++j) {
             float whi[32], wlo[32];
             uint16_t hh[32];
             for (int t = 0; t < 32; ++t) {
@@ -820,11 +821,11 @@ int upload_layer(xv_handle* h, Layer& L) {
               whi[t] = f16_to_f32(hh[t]);
               wlo[t] = wv - whi[t];
             }
-            unsigned char* pm = &wm[((((size_t)nb * ncb + cb) * 8 + j) * 2 + ct) * main_ct];
+            unsigned char* pm = &wm[((((size_t)nb * ncb + cb) * (4 * NQ) + j) * 2 + ct) * main_ct];
             for (int kc = 0; kc < 4; ++kc) memcpy(pm + (16 * kc + r16) * 16, &hh[8 * kc], 16);
             const int ln = 16 * (j & 3) + r16;
             for (int term = 0; term < 2; ++term) {          // term 0 multiplies q6(hi) of the activations, term 1 q6(lo)
-              unsigned char* px = &wx[((((((size_t)nb * ncb + cb) * 2 + (j >> 2)) * 2 + term) * 2) + ct) * cross_ct];
+              unsigned char* px = &wx[((((((size_t)nb * ncb + cb) * NQ + (j >> 2)) * 2 + term) * 2) + ct) * cross_ct];
               unsigned char c24[24], sc;
               host_quant32(term == 0 ? wlo : whi, c24, &sc);
               memcpy(px + ln * 16, c24, 16);
@@ -948,10 +949,10 @@ int xv_finalize(xv_handle* h) {
       L.im2col = bf && op.in0 == 0;
       L.cin_pad = (L.im2col && L.w <= 9) ? (int)align_up(L.cin, 32) : 0;
       L.use_split = L.im2col || (bf && vin.frame_level && (L.w == 1 || (L.cin % 32 == 0 && L.w <= 9)));   // slab halo of the split kernel
-      // two-unit split: the 5- and 7-tap layers over whole 32-channel blocks (the first layer, K = 5 x 30, stays on the f16 kernel and writes
+      // two-unit split: the 5-, 7- and 9-tap layers over whole 32-channel blocks (the first layer, K = 5 x 30, stays on the f16 kernel and writes
       // the block format of its reader: gemm_bf16x3_w14p2_kernel<1, 3, true>)
-      L.use_f6 = h->desc.precision == XV_PREC_F16F6 && L.use_split && !L.im2col && (L.w == 5 || L.w == 7) && L.cin % 32 == 0 &&
-                 L.cout % 4 == 0;
+      L.use_f6 = h->desc.precision == XV_PREC_F16F6 && L.use_split && !L.im2col && (L.w == 5 || L.w == 7 || L.w == 9) &&
+                 L.cin % 32 == 0 && L.cout % 4 == 0;
     } else {      // grid convolutions: whole SB blocks per tap; conv0 goes through its own im2col
       L.use_split = bf && (L.mode == 4 || L.cin % 32 == 0);
     }
@@ -1435,15 +1436,15 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     const Op& pop = h->ops[prod->op];
     if (pop.kind != OP_GEMM) continue;
     const Layer& PL = h->layers[pop.layer];
-    // producers that can write the format: another two-unit layer, or a >= 5-tap layer of the f16 kernel (its <1, 3, true> form;
-    // no K-split tail there: the tail's reduce kernel writes split-blocked rows)
-    const bool f16_multitap = PL.mode == 0 && PL.use_split && !PL.use_f6 && PL.w >= 5 && PL.w <= 9 && (PL.im2col ? PL.cin_pad > 0 : PL.cin % 32 == 0) &&
-                              prod->fuse_att == 0 && !prod->fuse_pool;
-    if (!(PL.use_f6 || f16_multitap) || prod->to_out || prod->out_off >= 0 || prod->out_sb_off < 0 || prod->stage != PL.final_stage() ||
+    // producers that can write the format: another two-unit layer, or a layer of the f16 kernels with one tap (the dense layers
+    // between the convolutions of the extended TDNN) or >= 5 taps -- their EPI = 3 forms; a K-split tail of theirs is finished by the
+    // two-unit kernel's reduce (launch_f6v2_tail_reduce)
+    const bool f16_layer = PL.mode == 0 && PL.use_split && !PL.use_f6 && (PL.w == 1 ? !PL.im2col : PL.w >= 5 && PL.w <= 9) &&
+                           (PL.im2col ? PL.cin_pad > 0 : PL.cin % 32 == 0) && prod->fuse_att == 0 && !prod->fuse_pool;
+    if (!(PL.use_f6 || f16_layer) || prod->to_out || prod->out_off >= 0 || prod->out_sb_off < 0 || prod->stage != PL.final_stage() ||
         pop.in1 > 0)
       continue;
     prod->out_f6 = true;
-    if (f16_multitap) { prod->tail_mt = 0; prod->ksplit = 1; }
     cs.in_f6 = true;
   }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-layer hipEvent times of the default forward, several rounds (quick look while tuning).  usage: layer_times.py [att|resnet] [precision]"""
+"""Per-layer hipEvent times of the default forward, several rounds (quick look while tuning).  usage: layer_times.py [tdnn|att|etdnn|resnet] [precision]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,10 @@ if net == "resnet":
     params, dim, B = Params(**dict(synth.RESNET_PARAMS)), 40, 64
     weights = synth.synth_resnet_weights(params, seed=0)
 else:
-    params, dim, B = Params(**dict(synth.TDNN_ATT_PARAMS if net == "att" else synth.TDNN_STAT_PARAMS)), 30, 256
+    base = dict(synth.TDNN_ATT_PARAMS if net == "att" else synth.TDNN_STAT_PARAMS)
+    if net == "etdnn":
+        base.update(network_type="extended_tdnn", embedding_node="tdnn12_dense")
+    params, dim, B = Params(**base), 30, 256
     weights = synth.synth_weights(params, dim, seed=0)
 feats = torch.from_numpy(np.concatenate(synth.synth_features(B, 300, dim, seed=3))).cuda()
 offs = np.arange(B + 1, dtype=np.int32) * 300
