@@ -353,9 +353,8 @@ def main():
               file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # The bench runs what a default invocation of the library, the CLI and the launcher runs (trainer.default_precision: f16f6 for the
-    # TDNN, bf16x3 for the extended TDNN and the ResNet); --precision / XVEC_PRECISION override.  The default line also carries the
-    # rate of the full-range precision (value_bf16x3).
+    # The bench runs what a default invocation of the library, the CLI and the launcher runs (trainer.default_precision: f16f6);
+    # --precision / XVEC_PRECISION override.  The default line also carries the rate of the full-range precision (value_bf16x3).
     precision = args.precision or trainer_mod.default_precision(args.network)
 
     base = synth.TDNN_ATT_PARAMS if args.pooling == "self_attention" else synth.TDNN_STAT_PARAMS

@@ -198,7 +198,7 @@ def test_resnet18_full_width_xvector(precision):
     tr.close()
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+@pytest.mark.parametrize("precision", ["bf16x3", "f16f6", "f32"])
 def test_resnet18_full_width_baseline_geometry(precision):
     """config 5 at its BASELINE geometry: full width (13.5 M parameters), 40-dim x 300-frame utterances (B = 2; the float64 oracle
     on one of them takes a few seconds), plus a 301-frame neighbour in the pack so that the utterance checked does not start the
@@ -267,7 +267,7 @@ def test_ragged_batch_matches_per_utterance(stat_model, precision):
     tr.close()
 
 
-@pytest.mark.parametrize("width,precision", [(8, "f32"), (32, "f32"), (32, "bf16x3"), (32, "f16x3")])
+@pytest.mark.parametrize("width,precision", [(8, "f32"), (32, "f32"), (32, "bf16x3"), (32, "f16x3"), (32, "f16f6")])
 def test_resnet18_time_stride_every_block(width, precision):
     """resnet_time_stride (model/resnet.py:187,239,244,249): stride 2 along time in the first block of stages 2-4 under
     TensorFlow's 'same' padding, whose placement depends on the parity of each utterance's length (even: 0 before / 1

@@ -228,4 +228,4 @@ def test_asm_guard_catches_an_in_flight_register_and_a_compiler_load(repo_root):
     if os.path.isfile(rep):
         rows = [l for l in open(rep) if l.startswith("_Z")]
         assert len(rows) >= 20 and all(l.rstrip().endswith("violations 0") for l in rows)
-        assert sum("gemm_f6v2_kernel" in l and "all-paths" in l for l in rows) == 6      # 5, 7, 9 taps x two output formats
+        assert sum("gemm_f6v2_kernel" in l and "all-paths" in l for l in rows) == 8      # 5, 7, 9 taps x two output formats + the two ResNet forms

@@ -953,7 +953,7 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
           reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<1, false>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<1, true>),
           reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<2, false>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<2, true>),
           reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, false, true>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<0, true, true>),
-          reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<3, true>)};
+          reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<3, true>), reinterpret_cast<const void*>(gemm_bf16x3_w1p3_kernel<3, true, true>)};
       for (const void* k : kernels3) {
         r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemw1p3);
         if (r != hipSuccess) return r;
@@ -1021,6 +1021,11 @@ hipError_t launch_gemm_bf16x3(const GemmArgs& a_in, hipStream_t s) {
 #endif
   if (a.arow) {                                 // gathered grid rows (ResNet convolutions without border rows)
     if (w != 1 || tail || !a.a_pitch || a.pool_part) return hipErrorInvalidValue;
+    if (a.ysb_f6) {                             // the reader is a two-unit ResNet convolution: its block format, nothing else
+      if (!a.f16 || !a.Ysb || a.Y || a.R) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<3, true, true>), grid, block, smemw1p3, s, a, nMain, nNt);
+      return hipGetLastError();
+    }
     if (a.f16) hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, true, true>), grid, block, smemw1p3, s, a, nMain, nNt);
     else       hipLaunchKernelGGL((gemm_bf16x3_w1p3_kernel<0, false, true>), grid, block, smemw1p3, s, a, nMain, nNt);
     return hipGetLastError();

@@ -58,9 +58,9 @@ struct WSet { f16x8 w[2][2]; };                    // [tap of the pair][channel 
 #define V2_WAITW2(N, W) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(W.w[0][0]), "+v"(W.w[0][1]), "+v"(W.w[1][0]), "+v"(W.w[1][1]))
 #define V2_WAITW1(N, W) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(W.w[0][0]), "+v"(W.w[0][1]))
 
-template <int NTAPS, bool OUT_F6>
-__device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, char* smem, int cb_begin, int cb_end, bool slice) {
-  static_assert(NTAPS == 5 || NTAPS == 7 || NTAPS == 9, "taps");
+template <int NTAPS, bool OUT_F6, bool RES>
+__device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, char* smem, int cb_begin, int cb_end, bool slice, int bin = 0) {
+  static_assert(NTAPS == 3 || NTAPS == 5 || NTAPS == 7 || NTAPS == 9, "taps");
   constexpr int NQ = (NTAPS + 3) / 4;    // macro steps (groups of four taps) per channel block
   constexpr int NGRP = v2_groups(NTAPS), V2_DA_BYTES = v2_slab_bytes(NTAPS);
   constexpr int NSLOT = 2;               // fragment slots per phase: tile g + 1 is read while tile g multiplies
@@ -79,7 +79,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   // A DMA piece = uniform base (scalar: tile row 8 g, channel block) + this lane's offset (its row of the eight, the chunk its LDS
   // position holds); only bit 1 of f2 depends on the piece, so the offset of an odd piece is the even one with chunk bit 1 flipped
   // where the position holds a chunk of the upper half.
-  const char* Abase = reinterpret_cast<const char*>(p.Xsb) + (int64_t)m0 * a_row_bytes;
+  const char* Abase = reinterpret_cast<const char*>(p.Xsb) + (int64_t)m0 * a_row_bytes + (NTAPS == 3 ? (int64_t)bin * p.bin_x_bytes : 0);
   // The loop keeps ONE lane-dependent register (the lane id): every per-lane offset below is recomputed from it where it is used
   // (a handful of VALU operations per phase, which the matrix pipe hides) instead of living in ~15 loop-invariant registers --
   // the difference between fitting 168 registers and spilling.  The empty asm makes the value opaque, so the compiler cannot
@@ -143,7 +143,8 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     return r * V2_DROW + (((l >> 4) ^ (((r >> 1) & 3) << 1)) << 4);
   };
   auto cross_off = [&](int l, int q) __attribute__((always_inline)) {
-    const int rx = (l & 15) + 4 * q + (l >> 4), px = rx >> 1;
+    // (three taps: the fourth K group has zero weights; it reads the rows of tap 2 again, which are real rows of the value)
+    const int rx = (l & 15) + (NTAPS == 3 ? min(l >> 4, 2) : 4 * q + (l >> 4)), px = rx >> 1;
     const int sx = (((px >> 1) & 1) << 2) | (((px >> 2) & 1) << 1) | (px & 1);
     return rx * V2_DROW + ((4 ^ sx) << 4);
   };
@@ -209,7 +210,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   for (int g = wave; g < NGRP; g += 4) dma_a(cb_begin, cb_begin & 1, g, lane_now());
   load_x(XA, cb_begin, 0, 0);
   load_x(XB, cb_begin, 0, 1);
-  if (NTAPS == 7) load_w2(WA, cb_begin, 0);
+  if (NTAPS == 7 || NTAPS == 3) load_w2(WA, cb_begin, 0);
   else load_w2(WB, cb_begin, 2);           // (5 and 9 taps issue WA = taps 0, 1 at the top of the channel block)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -225,7 +226,26 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   auto body = [&](int cb, auto last_tag) __attribute__((always_inline)) {
     constexpr bool last = decltype(last_tag)::value;
     const int nx = cb + 1;
-    if constexpr (NTAPS == 7) {
+    if constexpr (NTAPS == 3) {
+      // The 3 x 3 convolutions of the ResNet stages as a three-tap convolution along time over 3 C channels (the three frequency
+      // taps of a kernel row are one contiguous run of the zero-bordered grid: csrc/grid.hip).  One macro step per channel block:
+      //   3 taps  XA0: WB(2) x2, slab x5 | XB0: XA' x4 | M01: XB' x4 | M2: WA(0,1)' x4
+      //   waits   XA0 8    XB0 11 (6)    M01 11 (2)    M2 8 (0)      (M2: 13 would do for WB; 8 also lands the slab before the barrier)
+      V2_WAITX(8, XA);
+      load_w1(WB, cb, 2);
+      if constexpr (!last) dma_next(cb);
+      __builtin_amdgcn_sched_barrier(0);
+      x_phase(XA, cb, 0, 0);
+      if constexpr (!last) { V2_WAITX(11, XB); load_x(XA, nx, 0, 0); } else { V2_WAITX(6, XB); }
+      __builtin_amdgcn_sched_barrier(0);
+      x_phase(XB, cb, 0, 1);
+      if constexpr (!last) { V2_WAITW2(11, WA); load_x(XB, nx, 0, 1); } else { V2_WAITW2(2, WA); }
+      __builtin_amdgcn_sched_barrier(0);
+      m_phase(WA, cb, 0, 2);
+      if constexpr (!last) { V2_WAITW1(8, WB); load_w2(WA, nx, 0); } else { V2_WAITW1(0, WB); }
+      __builtin_amdgcn_sched_barrier(0);
+      m_phase(WB, cb, 2, 1);
+    } else if constexpr (NTAPS == 7) {
       V2_WAITX(8, XA);
       if constexpr (!last) dma_next(cb);
       load_w2(WB, cb, 2);
@@ -349,7 +369,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   __builtin_amdgcn_sched_barrier(0);
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
-  if (slice) {
+  if (NTAPS != 3 && slice) {               // (the three-tap ResNet form has no K-split tail)
     // K-split slice of a tail tile: the raw accumulators go to the slice's rows of GemmArgs::partial (p.Y / p.ldy were pointed there
     // by the kernel); 16-byte stores straight from the accumulator layout (lane & 15 -> frame, 4 * (lane >> 4) .. + 3 -> channels)
     const int c16e = lane_e & 15, g4e = lane_e >> 4;
@@ -361,13 +381,27 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     return;
   }
   // one epilogue per instantiation (both in one kernel cost 20 spilled accumulators at the loop exit)
-  if constexpr (OUT_F6) store_wave_tile_n32_f6(p, acc, m0, n0 + wave * 32, lane_e, wave, smem);
-  else store_wave_tile_n32<64, true>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem);
+  if constexpr (NTAPS == 3) {
+    // the bin's output rows: rowmap[m] + bin, as pointer offsets (taken here, behind the loop, so that nothing derived from them
+    // lives through it)
+    GemmArgs q = p;
+    const int b = __builtin_amdgcn_readfirstlane(bin);
+    if (p.Ysb) q.Ysb = reinterpret_cast<char*>(p.Ysb) + (int64_t)b * p.ldsb * 4;
+    if (p.Y) q.Y = p.Y + (int64_t)b * p.ldy;
+    if (p.R) q.R = p.R + (int64_t)b * p.ldr;
+    if constexpr (RES) store_wave_tile_n32_res(q, acc, m0, n0 + wave * 32, lane_e, wave, smem);
+    else store_wave_tile_n32_f6(q, acc, m0, n0 + wave * 32, lane_e, wave, smem);
+  } else {
+    if constexpr (OUT_F6) store_wave_tile_n32_f6(p, acc, m0, n0 + wave * 32, lane_e, wave, smem);
+    else store_wave_tile_n32<64, true>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem);
+  }
 }
 
 // Workgroups [0, nMt * nNt) are whole tiles; with S > 0 the grid continues with the K-split slices of the tail tiles exactly as in
 // gemm_bf16x3_w14p2_kernel (raw partial sums to GemmArgs::partial, finished by f6v2_tail_reduce_kernel).
-template <int NTAPS, bool OUT_F6>
+// GemmArgs::nbin > 1 (the ResNet form): an "M tile" is a pair (128 time rows, frequency bin); bin b reads its windows b * bin_x_bytes
+// further into the rows of A and writes output rows rowmap[m] + b (no K-split tail in this form).
+template <int NTAPS, bool OUT_F6, bool RES = false>
 __global__ __launch_bounds__(256, 3) void gemm_f6v2_kernel(GemmArgs p, int nMt, int nNt, int S) {
   extern __shared__ __attribute__((aligned(16))) char smem_v2[];
   int mt, nt, cb_begin = 0, cb_end = p.cin >> 5;
@@ -387,92 +421,92 @@ __global__ __launch_bounds__(256, 3) void gemm_f6v2_kernel(GemmArgs p, int nMt, 
     mt = tile / nNt;
     nt = tile - mt * nNt;
   }
-  f6v2_tile<NTAPS, OUT_F6>(p, mt * V2_BM, nt * V2_BN, smem_v2, cb_begin, cb_end, slice);
+  int bin = 0;
+  if (NTAPS == 3 && p.nbin > 1) {
+    bin = mt % p.nbin;
+    mt /= p.nbin;
+  }
+  f6v2_tile<NTAPS, OUT_F6, RES>(p, mt * V2_BM, nt * V2_BN, smem_v2, cb_begin, cb_end, slice, bin);
 }
 
-// One thread per (tail row, 32-channel block): ordered sum of the K slices, BN scale / shift + activation, then fp32 and / or the
-// split-blocked row or the two-unit block (what the layer's whole tiles write through their epilogues).
+// One thread per (tail row, 4 channels), the eight lanes of a 32-channel block side by side: ordered sum of the K slices, BN scale /
+// shift + activation, then fp32 and / or the split-blocked row or the two-unit block (what the layer's whole tiles write through
+// their epilogues).  The block's two maxima are taken over its eight lanes, every lane codes its four values into 24 bits, and
+// lanes 0-5 assemble dword j of the 192-bit code string from two neighbours' pieces.  (One thread per block, everything serial,
+// took 14-16 us per layer for 1.4 % of its work.)  Every branch below is uniform over a group of eight lanes.
 template <int S>
-__global__ __launch_bounds__(64) void f6v2_tail_reduce_kernel(GemmArgs p, int mt0) {
-  const int nblk = p.Npad >> 5;
+__global__ __launch_bounds__(256) void f6v2_tail_reduce_kernel(GemmArgs p, int mt0) {
+  const int quads = p.Npad >> 2;            // Npad % 32 == 0: a group of eight lanes never straddles two rows
   const int64_t rows = (int64_t)p.tail_mt * V2_BM;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * nblk) return;
-  const int64_t r = i / nblk;
-  const int n0 = (int)(i - r * nblk) * 32;
+  if (i >= rows * quads) return;
+  const int64_t r = i / quads;
+  const int n = (int)(i - r * quads) * 4;
   const int64_t m = (int64_t)mt0 * V2_BM + r;
   if (m >= p.M) return;
   bool zero;
   const int orow = out_row(p, (int)m, zero);
   if (orow < 0) return;
-  float v[32];
+  // S is a template parameter: the S loads of a thread are issued together; the slices are still added in ascending order
+  f32x4 t[S];
 #pragma unroll
-  for (int e = 0; e < 32; ++e) v[e] = 0.f;
-  // S is a template parameter: the S x 8 loads of a thread are issued together (as a run-time loop they were S dependent
-  // round trips: 14-16 us per layer for 1.4 % of its work); the slices are still added in ascending order
-  f32x4 t[S][8];
+  for (int s = 0; s < S; ++s) t[s] = *reinterpret_cast<const f32x4*>(p.partial + ((int64_t)s * rows + r) * p.Npad + n);
+  f32x4 acc = t[0];
 #pragma unroll
-  for (int s = 0; s < S; ++s) {
-    const float* src = p.partial + ((int64_t)s * rows + r) * p.Npad + n0;
+  for (int s = 1; s < S; ++s) acc += t[s];
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) t[s][q] = *reinterpret_cast<const f32x4*>(src + 4 * q);
-  }
-#pragma unroll
-  for (int s = 0; s < S; ++s)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { v[4 * q] += t[s][q][0]; v[4 * q + 1] += t[s][q][1]; v[4 * q + 2] += t[s][q][2]; v[4 * q + 3] += t[s][q][3]; }
-#pragma unroll
-  for (int e = 0; e < 32; ++e) {
-    const int n = n0 + e;
-    v[e] = (n < p.N && !zero) ? apply_act(fmaf(v[e], p.scale[n], p.shift[n]), p.act, p.alpha ? p.alpha[n] : 0.f) : 0.f;
-  }
-  if (p.Y && n0 < p.N) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (n0 + 4 * q < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n0 + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-  }
-  if (!p.Ysb || n0 >= p.ldsb) return;
-  uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n0 >> 5) * 128);
-  uint32_t hw[16], lw[16];
-  float hf[32], lf[32], mh = 0.f, ml = 0.f, mx = 0.f;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const float a = v[2 * e] * p.sb_mul, b = v[2 * e + 1] * p.sb_mul;
-    split2t<true>(a, b, hw[e], lw[e]);
-    const f16x2_t hh = __builtin_bit_cast(f16x2_t, hw[e]);
-    hf[2 * e] = (float)hh[0]; hf[2 * e + 1] = (float)hh[1];
-    lf[2 * e] = a - hf[2 * e]; lf[2 * e + 1] = b - hf[2 * e + 1];
-    mh = fmaxf(mh, fmaxf(fabsf(hf[2 * e]), fabsf(hf[2 * e + 1])));
-    ml = fmaxf(ml, fmaxf(fabsf(lf[2 * e]), fabsf(lf[2 * e + 1])));
-    mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
-  }
-  ovf_report(p.ovf, mx);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) dst[c] = uint4{hw[4 * c], hw[4 * c + 1], hw[4 * c + 2], hw[4 * c + 3]};
+  for (int e = 0; e < 4; ++e)
+    if (n + e < p.N && !zero) v[e] = apply_act(fmaf(acc[e], p.scale[n + e], p.shift[n + e]), p.act, p.alpha ? p.alpha[n + e] : 0.f);
+  if (p.Y && n < p.N) *reinterpret_cast<f32x4*>(p.Y + (int64_t)orow * p.ldy + n) = v;     // N % 4 == 0
+  if (!p.Ysb || n >= p.ldsb) return;
+  char* dst = reinterpret_cast<char*>(p.Ysb) + (int64_t)orow * p.ldsb * 4 + (n >> 5) * 128;
+  const int j = (n & 31) >> 2;              // this lane's place among the eight of its block
+  v *= p.sb_mul;
+  uint32_t h01, l01, h23, l23;
+  split2t<true>(v[0], v[1], h01, l01);
+  split2t<true>(v[2], v[3], h23, l23);
+  ovf_report(p.ovf, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  *reinterpret_cast<uint2*>(dst + 8 * j) = make_uint2(h01, h23);
   if (!p.ysb_f6) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dst[4 + c] = uint4{lw[4 * c], lw[4 * c + 1], lw[4 * c + 2], lw[4 * c + 3]};
+    *reinterpret_cast<uint2*>(dst + 64 + 8 * j) = make_uint2(l01, l23);
     return;
+  }
+  const f16x2_t ha = __builtin_bit_cast(f16x2_t, h01), hb = __builtin_bit_cast(f16x2_t, h23);
+  const float hf[4] = {(float)ha[0], (float)ha[1], (float)hb[0], (float)hb[1]};
+  float lf[4], mh = 0.f, ml = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    lf[e] = v[e] - hf[e];
+    mh = fmaxf(mh, fabsf(hf[e]));
+    ml = fmaxf(ml, fabsf(lf[e]));
+  }
+#pragma unroll
+  for (int d = 1; d < 8; d <<= 1) {
+    mh = fmaxf(mh, __shfl_xor(mh, d, 8));
+    ml = fmaxf(ml, __shfl_xor(ml, d, 8));
   }
   uint32_t bh, bl;
   const float ih = e8m0_of(mh, bh), il = e8m0_of(ml, bl);
-  uint32_t ch[6] = {0, 0, 0, 0, 0, 0}, cl[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t ph = 0, pl = 0;                  // codes 4 j .. 4 j + 3 = bits 24 j .. 24 j + 23 of the block's code string
 #pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    const uint32_t a = e2m3_code(hf[k], ih), b = e2m3_code(lf[k], il);
-    const int bit = 6 * k, w = bit >> 5, sh = bit & 31;
-    ch[w] |= a << sh; cl[w] |= b << sh;
-    if (sh > 26) { ch[w + 1] |= a >> (32 - sh); cl[w + 1] |= b >> (32 - sh); }
+  for (int e = 0; e < 4; ++e) {
+    ph |= e2m3_code(hf[e], ih) << (6 * e);
+    pl |= e2m3_code(lf[e], il) << (6 * e);
   }
+  // dword j of the string (j < 6) = bits 32 j .. 32 j + 31: piece a = 32 j / 24 from bit 32 j % 24 on, then piece a + 1
+  const int a = (4 * j) / 3, off = 8 * (j % 3);
+  const uint32_t ha0 = __shfl(ph, a & 7, 8), ha1 = __shfl(ph, (a + 1) & 7, 8);
+  const uint32_t la0 = __shfl(pl, a & 7, 8), la1 = __shfl(pl, (a + 1) & 7, 8);
   const uint32_t sc2 = bh | (bl << 8);
-  dst[4] = uint4{ch[0], ch[1], ch[2], ch[3]};
-  dst[5] = uint4{cl[0], cl[1], cl[2], cl[3]};
-  dst[6] = uint4{ch[4], ch[5], sc2, 0u};
-  dst[7] = uint4{cl[4], cl[5], sc2, 0u};
+  const uint32_t wh = j < 6 ? (ha0 >> off) | (ha1 << (24 - off)) : (j == 6 ? sc2 : 0u);
+  const uint32_t wl = j < 6 ? (la0 >> off) | (la1 << (24 - off)) : (j == 6 ? sc2 : 0u);
+  // chunk 4 / 5: code dwords 0-3 of hi / lo; chunk 6 / 7: {code dwords 4, 5 | scale dword | pad}
+  const int oh = j < 4 ? 64 + 4 * j : 96 + 4 * (j - 4);
+  *reinterpret_cast<uint32_t*>(dst + oh) = wh;
+  *reinterpret_cast<uint32_t*>(dst + oh + 16) = wl;
   if (m == p.M - 1) {                      // eight zero rows behind the value's last row (store_wave_tile_n32_f6)
-    for (int k = 1; k <= 8; ++k)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) dst[(int64_t)k * (p.ldsb >> 2) + c] = uint4{0u, 0u, 0u, 0u};
+    for (int k = 1; k <= 8; ++k) *reinterpret_cast<uint4*>(dst + (int64_t)k * p.ldsb * 4 + 16 * j) = uint4{0u, 0u, 0u, 0u};
   }
 }
 
@@ -488,7 +522,9 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   const int taps = a.cin > 0 ? a.K / a.cin : 0;
   // Only the widths the reference's graphs contain are instantiated (tdnn: 5, 5, 7; extended tdnn: 5, 5, 7, 9).
-  if ((taps != 5 && taps != 7 && taps != 9) || (a.cin & 31) || a.ldsbx != a.cin || !a.Wx6 || !a.Wfr || a.a_pitch || a.pool_part || a.R || (a.N & 3))
+  const bool bins = a.nbin > 1;             // the ResNet form: three taps along time, the rows wider than the window (ldsbx > cin)
+  if ((taps != 3 && taps != 5 && taps != 7 && taps != 9) || (a.cin & 31) || (bins ? a.ldsbx < a.cin || taps != 3 : a.ldsbx != a.cin || taps == 3) ||
+      !a.Wx6 || !a.Wfr || a.a_pitch || a.pool_part || (a.R && !bins) || (a.N & 3))
     return hipErrorInvalidValue;
   static std::mutex mu;
   static bool attr_set[64] = {};
@@ -500,7 +536,8 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
     if (!attr_set[dev & 63]) {
       const void* ks[] = {reinterpret_cast<const void*>(gemm_f6v2_kernel<5, false>), reinterpret_cast<const void*>(gemm_f6v2_kernel<7, false>),
                           reinterpret_cast<const void*>(gemm_f6v2_kernel<5, true>), reinterpret_cast<const void*>(gemm_f6v2_kernel<7, true>),
-                          reinterpret_cast<const void*>(gemm_f6v2_kernel<9, false>), reinterpret_cast<const void*>(gemm_f6v2_kernel<9, true>)};
+                          reinterpret_cast<const void*>(gemm_f6v2_kernel<9, false>), reinterpret_cast<const void*>(gemm_f6v2_kernel<9, true>),
+                          reinterpret_cast<const void*>(gemm_f6v2_kernel<3, true>), reinterpret_cast<const void*>(gemm_f6v2_kernel<3, true, true>)};
       for (const void* k : ks) {
         const hipError_t r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * v2_slab_bytes(9));
         if (r != hipSuccess) return r;
@@ -508,14 +545,17 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
       attr_set[dev & 63] = true;
     }
   }
-  const int nMt = (a.M + V2_BM - 1) / V2_BM, nNt = a.Npad / V2_BN, ncb = a.cin >> 5;
-  const bool tail = a.tail_mt > 0 && (a.ksplit == 2 || a.ksplit == 4 || a.ksplit == 8) && a.partial && a.tail_mt < nMt && ncb % a.ksplit == 0;
+  const int nMt = ((a.M + V2_BM - 1) / V2_BM) * (bins ? a.nbin : 1), nNt = a.Npad / V2_BN, ncb = a.cin >> 5;
+  const bool tail = !bins && a.tail_mt > 0 && (a.ksplit == 2 || a.ksplit == 4 || a.ksplit == 8) && a.partial && a.tail_mt < nMt && ncb % a.ksplit == 0;
   const int nMain = tail ? nMt - a.tail_mt : nMt;
   const int S = tail ? a.ksplit : 0;
   const dim3 grid(nMain * nNt + (tail ? a.tail_mt * nNt * a.ksplit : 0)), block(256);
-  const bool out_f6 = a.ysb_f6 && a.Ysb && !a.Y;
-  if (a.ysb_f6 && !out_f6) return hipErrorInvalidValue;        // the block format is written only when it is the layer's one output
-  if (taps == 5) {
+  const bool out_f6 = a.ysb_f6 && a.Ysb && (bins || !a.Y);
+  if (a.ysb_f6 && !out_f6) return hipErrorInvalidValue;        // (TDNN forms: the block format is written only when it is the layer's one output)
+  if (taps == 3) {                       // <3, true, true>: the residual epilogue, block or split-blocked output by GemmArgs::ysb_f6
+    if (out_f6 && !a.R && !a.Y) hipLaunchKernelGGL((gemm_f6v2_kernel<3, true>), grid, block, smem, s, a, nMain, nNt, S);
+    else                        hipLaunchKernelGGL((gemm_f6v2_kernel<3, true, true>), grid, block, smem, s, a, nMain, nNt, S);
+  } else if (taps == 5) {
     if (out_f6) hipLaunchKernelGGL((gemm_f6v2_kernel<5, true>), grid, block, smem, s, a, nMain, nNt, S);
     else        hipLaunchKernelGGL((gemm_f6v2_kernel<5, false>), grid, block, smem, s, a, nMain, nNt, S);
   } else if (taps == 7) {
@@ -533,8 +573,8 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
 // The reduce of a K-split tail (rows from M tile nMain on; a.partial, a.tail_mt, a.ksplit as planned) with the split-blocked or the
 // two-unit block output; also the tail of a one-tap or f16 multi-tap layer that writes the block format (gemm_bf16x3.hip).
 hipError_t launch_f6v2_tail_reduce(const GemmArgs& a, int nMain, hipStream_t s) {
-  const int64_t total = (int64_t)a.tail_mt * V2_BM * (a.Npad >> 5);
-  const dim3 rgrid((unsigned)((total + 63) / 64)), rblock(64);
+  const int64_t total = (int64_t)a.tail_mt * V2_BM * (a.Npad >> 2);
+  const dim3 rgrid((unsigned)((total + 255) / 256)), rblock(256);
   switch (a.ksplit) {
     case 2: hipLaunchKernelGGL(f6v2_tail_reduce_kernel<2>, rgrid, rblock, 0, s, a, nMain); break;
     case 4: hipLaunchKernelGGL(f6v2_tail_reduce_kernel<4>, rgrid, rblock, 0, s, a, nMain); break;

@@ -151,6 +151,19 @@ __global__ void rowmap_rows_kernel(const int32_t* __restrict__ off0, int B, int3
   rowmap[m] = (t >= 1 && t <= L) ? off0[b] + t - 1 : -1;
 }
 
+// Two-unit form of the stride-1 3 x 3 convolutions (gemm_f6v2_kernel, three taps along time): GEMM row m = padded time row m of the
+// input grid = the top row of the windows of output frame t = m - (off0[b] + 2 b); the kernel's frequency bin j writes output row
+// rowmap[m] + j of a value whose base pointer is advanced by one position, i.e. grid position (t + 1, j + 1).  The two bottom
+// rows of an utterance start no window.
+__global__ void rowmap_trows_kernel(const int32_t* __restrict__ off0, int B, int So, int32_t* __restrict__ rowmap, int64_t M) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int b = find_utt(off0, B, 1, m);
+  const int t = (int)(m - (off0[b] + 2 * b));
+  const int L = off0[b + 1] - off0[b];
+  rowmap[m] = t < L ? (int32_t)((m + 1) * So) : -1;
+}
+
 // conv0: the GEMM rows ARE the output positions (pitch S); border positions are written as zeros
 __global__ void rowmap_interior_kernel(const int32_t* __restrict__ off0, int B, int F, int S, int32_t* __restrict__ rowmap,
                                        int64_t M) {
@@ -376,6 +389,12 @@ hipError_t launch_conv0_direct(const float* x, int64_t ldx, const int32_t* off0,
   if (C > kConv0MaxC || F > kConv0MaxF || (C & 7) || rows * S != P) return hipErrorInvalidValue;
   hipLaunchKernelGGL(conv0_direct_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, ldx, off0, B, F, S, C, wdir, act, alpha, y,
                      static_cast<char*>(ysb), ldsb, f16, ovf, sb_mul);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_rowmap_trows(const int32_t* off0, int B, int So, int32_t* rowmap, int64_t M, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rowmap_trows_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, off0, B, So, rowmap, M);
   return hipGetLastError();
 }
 

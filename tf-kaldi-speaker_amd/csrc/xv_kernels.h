@@ -50,6 +50,8 @@ struct GemmArgs {
   int slab3 = 1;               // one-tap layers: three slab buffers / slabs two steps ahead (gemm_bf16x3_w1p3_kernel); 0 = the
                                // two-buffer kernel (same arithmetic, bit-identical results; xv_set_option "slab3")
   int* ovf = nullptr;          // f16 only: set to 1 when a value beyond the fp16 range was converted (checked by the host)
+  int nbin = 0;                // gemm_f6v2_kernel, ResNet form: frequency bins per time row (a second tile dimension), and the byte
+  int64_t bin_x_bytes = 0;     // offset of a bin's windows inside a row of A; bin b writes output rows rowmap[m] + b
   float sb_mul = 1.f;          // fp16 split formats: the split-blocked / fp6-block output holds y * sb_mul, a per-layer power of two that
                                // keeps the activations' low halves normal (|y * sb_mul| ~ 2^4 rms; the reader's per-channel scale
                                // carries 1 / sb_mul exactly: xvec_api.hip, act_exponent).  The fp32 output Y is never scaled.
@@ -176,6 +178,7 @@ hipError_t launch_build_rowmap_grid_compact(const int32_t* off_in, const int32_t
 hipError_t launch_grid_zero_border(const int32_t* off0, int B, int64_t frames, int F, int S, int chunks_y, int chunks_sb,
                                    float* y, void* ysb, hipStream_t s);
 hipError_t launch_build_rowmap_rows(const int32_t* off0, int B, int32_t* rowmap, int64_t M, hipStream_t s);
+hipError_t launch_build_rowmap_trows(const int32_t* off0, int B, int So, int32_t* rowmap, int64_t M, hipStream_t s);
 // rowmap of conv0 (rows = grid positions, pitch S): interior -> same position, border -> zeros at the same position
 hipError_t launch_build_rowmap_interior(const int32_t* off0, int B, int F, int S, int32_t* rowmap, int64_t M, hipStream_t s);
 // conv0 im2col: out SB row p (grid position of the OUTPUT), k = kh*3+kw < 9: x[t+kh-1][f+kw-1] or 0

@@ -150,6 +150,7 @@ struct xv_handle {
   // options (xv_set_option)
   int opt_pool_fusion = 1;                            // statistics pooling fused into the last frame layer's epilogue
   int opt_tail_split = 1;                             // K-split of the last, nearly empty round of GEMM tiles
+  int opt_grid_f6 = 1;                                // XV_PREC_F16F6: the stride-1 3 x 3 ResNet convolutions of >= 128 channels on the two-unit kernel
   int opt_slab3 = 1;                                  // one-tap GEMM layers on the three-slab-buffer kernel
   int opt_grid_compact = 1;                           // ResNet grid convolutions enumerate output bins only (split precisions)
   int opt_att_fusion = 1;                             // attention scores / weighted moments in the GEMM epilogues
@@ -204,6 +205,7 @@ struct PlanStep {
   int64_t frames_out = 0;       // total frames of the batch at the output's time level
   bool grid_cover = false;      // grid-valued output whose border is re-zeroed by zero-writing GEMM rows (no memset)
   bool out_f6 = false;          // XV_PREC_F16F6: this layer writes its split-blocked output in the block format of gemm_f16f6.hip ...
+  bool trows = false;           // two-unit form of a stride-1 3 x 3 grid convolution: GEMM rows = padded time rows x frequency bins
   bool in_f6 = false;           // ... because its only reader is this kind of layer, which then needs no conversion pass
   bool compact = false;         // grid convolution whose GEMM rows are the output bins only (csrc/grid.hip, compact form)
   int arow = -1;                // compact: index into plan rowmaps of the window positions (GemmArgs::arow)
@@ -806,7 +808,10 @@ int upload_layer(xv_handle* h, Layer& L) {
       //   main  [Npad/32][cin/32][4 NQ taps][2 channel tiles][64 lanes = 16 * k-chunk + channel][8 x f16]
       //   cross [Npad/32][cin/32][NQ macro steps][2 terms: q6(w - f16(w)), q6(f16(w))][2 channel tiles] x { 64 x 16 B codes 0-15 |
       //         64 x 16 B {codes 16-23, scale dword (E8M0 in byte 0), pad} },  lane = 16 * (tap & 3) + channel: K group = tap inside the macro step
-      const int ncb = L.cin / 32, NQ = (L.w + 3) / 4;
+      // (a 3 x 3 grid convolution = three taps along time over the 3 cin contiguous channels of a kernel row: HWIO k-major is
+      //  already [kt][kf * cin + c][n])
+      const int fw = L.mode == 1 ? 3 : L.w, fcin = L.mode == 1 ? 3 * L.cin : L.cin;
+      const int ncb = fcin / 32, NQ = (fw + 3) / 4;
       const size_t main_ct = 64 * 16, cross_ct = 2 * 64 * 16;
       std::vector<unsigned char> wm((size_t)(L.Npad / 32) * ncb * (4 * NQ) * 2 * main_ct, 0), wx((size_t)(L.Npad / 32) * ncb * NQ * 2 * 2 * cross_ct, 0);
       for (int n = 0; n < L.Npad; ++n) {
@@ -816,7 +821,7 @@ int upload_layer(xv_handle* h, Layer& L) {
             float whi[32], wlo[32];
             uint16_t hh[32];
             for (int t = 0; t < 32; ++t) {
-              const float wv = (j < L.w && n < N) ? W[((size_t)j * L.cin + cb * 32 + t) * N + n] * wscale : 0.f;
+              const float wv = (j < fw && n < N) ? W[((size_t)j * fcin + cb * 32 + t) * N + n] * wscale : 0.f;
               hh[t] = f32_to_f16_rn(wv);
               whi[t] = f16_to_f32(hh[t]);
               wlo[t] = wv - whi[t];
@@ -955,6 +960,10 @@ int xv_finalize(xv_handle* h) {
                  L.cin % 32 == 0 && L.cout % 4 == 0;
     } else {      // grid convolutions: whole SB blocks per tap; conv0 goes through its own im2col
       L.use_split = bf && (L.mode == 4 || L.cin % 32 == 0);
+      // two-unit split of the stride-1 3 x 3 convolutions: three taps along time over the 3 C channels of a kernel row
+      // (gemm_f6v2_kernel<3, ...>); whole 128-channel tiles only (stage 1 of the default net, 64 channels, is HBM-bound anyway)
+      L.use_f6 = h->desc.precision == XV_PREC_F16F6 && h->opt_grid_f6 && L.mode == 1 && L.use_split && L.sw == 1 && L.st == 1 &&
+                 L.cin % 32 == 0 && L.cout % 128 == 0;
     }
   }
   if (h->desc.precision == XV_PREC_F16X3 || h->desc.precision == XV_PREC_F16F6) {
@@ -1018,6 +1027,7 @@ int xv_set_option(xv_handle* h, const char* name, int value) {
   else if (!strcmp(name, "tail_split")) h->opt_tail_split = value != 0;
   else if (!strcmp(name, "att_fusion")) h->opt_att_fusion = value != 0;
   else if (!strcmp(name, "slab3")) h->opt_slab3 = value != 0;
+  else if (!strcmp(name, "grid_f6")) h->opt_grid_f6 = value != 0;      // (before xv_finalize: it decides the weight formats)
   else if (!strcmp(name, "grid_compact")) h->opt_grid_compact = value != 0;
   else if (!strcmp(name, "profile_dominant")) h->opt_profile_dominant = value != 0;
   else return fail(h, XV_ERR_INVALID, "xv_set_option: unknown option '%s'", name);
@@ -1272,6 +1282,10 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       st.stage = st.to_out ? node.stage : L.final_stage();
       const int64_t padded_rows = Fl[st.lvl_in] + 2 * (int64_t)batch;   // input time rows incl. the two border rows per utterance
       if (L.mode == 0) st.M = (int)(st.rows_in - (L.w - 1));
+      else if (L.mode == 1 && L.use_f6) {
+        st.trows = true;                   // rows = padded time rows, frequency bins = a second tile dimension (csrc/grid.hip)
+        st.M = (int)padded_rows;
+      }
       else if ((L.mode == 1 || L.mode == 2) && L.use_split && h->opt_grid_compact &&
                st.rows_in * (int64_t)sb_ld(L.cin) * 4 < ((int64_t)1 << 32)) {
         st.compact = true;                 // rows = output bins; 32-bit byte offsets of the window positions
@@ -1282,7 +1296,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       else st.M = (int)(padded_rows * h->values[op.out].grid_S);     // conv0: one row per output grid position
       // does every border position of the output get a zero-writing GEMM row? (csrc/grid.hip)  If not the value is
       // zeroed as a whole before the layer runs.
-      if (st.compact) st.grid_cover = false;
+      if (st.compact || st.trows) st.grid_cover = false;
       else if (L.mode == 1 || L.mode == 2) st.grid_cover = L.st == 1 && h->values[op.in0].grid_S / L.sw == h->values[op.out].grid_S;
       else if (L.mode == 4) st.grid_cover = true;
       if (L.w > 1 || L.mode != 0) {
@@ -1308,7 +1322,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
         if (st.ksplit > 1) scratch = (int64_t)st.ksplit * st.M * L.Npad * 4;
       } else if (L.use_f6) {
         scratch = (st.rows_in + kSlackRows) * (int64_t)sb_ld(L.cin) * 4;      // the input in the block format of gemm_f16f6.hip
-        if (h->opt_tail_split && op.in1 <= 0) {
+        if (h->opt_tail_split && op.in1 <= 0 && L.mode == 0) {
           const int64_t part = gemm_bf16x3_tail_plan(st.M, L.Kpad, L.Npad, L.w, &st.tail_mt, &st.ksplit);
           if (part > 0) {
             step_scratch2 = align_up(part, kAlign);
@@ -1425,25 +1439,34 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
   for (PlanStep& cs : p->steps) {
     const Op& cop = h->ops[cs.op];
     if (cop.kind != OP_GEMM || !h->layers[cop.layer].use_f6) continue;
+    const bool grid = h->layers[cop.layer].mode == 1;
+    // readers of the value's SPLIT copy: every op that takes it as its first input; a second input is the fp32 residual of a ResNet
+    // block (another copy of the value) -- in the TDNN graphs it does not occur, and disqualifies as before
     int readers = 0;
     PlanStep* prod = nullptr;
     for (PlanStep& os : p->steps) {
       const Op& o = h->ops[os.op];
-      if (o.in0 == cop.in0 || o.in1 == cop.in0) ++readers;
+      if (o.in0 == cop.in0 || (!grid && o.in1 == cop.in0)) ++readers;
       if (o.out == cop.in0) prod = &os;
     }
     if (!prod || readers != 1) continue;
     const Op& pop = h->ops[prod->op];
     if (pop.kind != OP_GEMM) continue;
     const Layer& PL = h->layers[pop.layer];
-    // producers that can write the format: another two-unit layer, or a layer of the f16 kernels with one tap (the dense layers
-    // between the convolutions of the extended TDNN) or >= 5 taps -- their EPI = 3 forms; a K-split tail of theirs is finished by the
-    // two-unit kernel's reduce (launch_f6v2_tail_reduce)
-    const bool f16_layer = PL.mode == 0 && PL.use_split && !PL.use_f6 && (PL.w == 1 ? !PL.im2col : PL.w >= 5 && PL.w <= 9) &&
-                           (PL.im2col ? PL.cin_pad > 0 : PL.cin % 32 == 0) && prod->fuse_att == 0 && !prod->fuse_pool;
-    if (!(PL.use_f6 || f16_layer) || prod->to_out || prod->out_off >= 0 || prod->out_sb_off < 0 || prod->stage != PL.final_stage() ||
-        pop.in1 > 0)
-      continue;
+    if (prod->to_out || prod->out_sb_off < 0 || prod->stage != PL.final_stage()) continue;
+    if (grid) {
+      // producers: another two-unit grid layer (its residual epilogue also writes the fp32 copy and adds a residual), or a stride-2
+      // 3 x 3 convolution of the gathered f16 kernel (EPI = 3: the block format only)
+      const bool gather = PL.mode == 1 && !PL.use_f6 && PL.use_split && prod->compact && prod->out_off < 0 && pop.in1 <= 0;
+      if (!((PL.mode == 1 && PL.use_f6) || gather)) continue;
+    } else {
+      // producers that can write the format: another two-unit layer, or a layer of the f16 kernels with one tap (the dense layers
+      // between the convolutions of the extended TDNN) or >= 5 taps -- their EPI = 3 forms; a K-split tail of theirs is finished by the
+      // two-unit kernel's reduce (launch_f6v2_tail_reduce)
+      const bool f16_layer = PL.mode == 0 && PL.use_split && !PL.use_f6 && (PL.w == 1 ? !PL.im2col : PL.w >= 5 && PL.w <= 9) &&
+                             (PL.im2col ? PL.cin_pad > 0 : PL.cin % 32 == 0) && prod->fuse_att == 0 && !prod->fuse_pool;
+      if (!((PL.mode == 0 && PL.use_f6) || f16_layer) || prod->out_off >= 0 || pop.in1 > 0) continue;
+    }
     prod->out_f6 = true;
     cs.in_f6 = true;
   }
@@ -1503,6 +1526,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       const int32_t* doff = p->dev_offsets(st.lvl_in);
       int32_t* rm = static_cast<int32_t*>(p->d_rowmaps.p) + p->rowmap_off[st.rowmap];
       if (L.mode == 0) e = launch_build_rowmap(doff, batch, ctx_in, L.w, rm, st.M, s);
+      else if (st.trows) e = launch_build_rowmap_trows(doff, batch, h->values[op.out].grid_S, rm, st.M, s);
       else if (st.compact)
         e = launch_build_rowmap_grid_compact(doff, p->dev_offsets(st.lvl_out), batch, h->values[op.in0].grid_S,
                                              h->values[op.out].grid_S, L.Fout, L.sw, L.st, L.mode == 1 ? 3 : 1,
@@ -1655,7 +1679,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           // (whole-value clear: one more time row than the value has -- with the shared border column the 3x3 window of
           // the last bin of the last utterance's bottom border row reads position (L + 2, 0), just behind the grid)
           const size_t rows0 = st.grid_cover && L.mode != 4 ? head : (st.grid_cover ? 0 : (size_t)st.rows_out + vo.grid_S);
-          if (st.compact) {                 // border positions only
+          if (st.compact || st.trows) {     // border positions only
             XV_HIP(h, launch_grid_zero_border(p->dev_offsets(st.lvl_out), B, st.frames_out, vo.grid_F, vo.grid_S, L.cout / 4,
                                               sb_ld(L.cout) / 4, st.out_off >= 0 ? reinterpret_cast<float*>(ws + st.out_off) : nullptr,
                                               st.out_sb_off >= 0 ? ws + st.out_sb_off : nullptr, s));
@@ -1779,12 +1803,30 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
           a.ldsbx = sb_ld(L.cin);
           a.Wfr = L.wf6m.p;
           a.Wx6 = L.wf6x.p;
+          if (st.trows) {
+            // 3 x 3 on the zero-bordered grid as three taps along time: a GEMM row = one padded time row of Sin positions, the window
+            // of frequency bin j = the 3 cin contiguous channels from position j on; output row rowmap[m] + j of the value advanced by
+            // one position (csrc/grid.hip, rowmap_trows_kernel)
+            const int64_t Sin = h->values[op.in0].grid_S;
+            a.a_pitch = 0; a.a_off = 0; a.arow = nullptr; a.ntaps = 0; a.ktap = 0; a.tap_stride = 0;
+            a.ldsbx = Sin * L.cin;
+            a.cin = 3 * L.cin;
+            a.K = 9 * L.cin;
+            a.nbin = L.Fout;
+            a.bin_x_bytes = (int64_t)L.cin * 4;
+            if (a.Ysb) a.Ysb = static_cast<char*>(a.Ysb) + (int64_t)a.ldsb * 4;
+            if (a.Y) a.Y += a.ldy;
+            if (a.R) a.R += a.ldr;
+          }
           if (st.tail_mt > 0 && st.scratch2_off >= 0) {
             a.tail_mt = st.tail_mt;
             a.ksplit = st.ksplit;
             a.partial = reinterpret_cast<float*>(ws + st.scratch2_off);
           }
           XV_HIP(h, launch_gemm_f16f6(a, s));
+          if (st.unpad_to_out)
+            XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off_out, B, vo.grid_F, vo.grid_S, vo.cols,
+                                          st.frames_out, out, s));
           break;
         }
         if (L.use_split) {

@@ -29,4 +29,4 @@ for rnd in range(4):
     tr.profile_begin(8192)
     for _ in range(20): tr.predict_packed(feats, offs, out=out)
     recs, _ = tr.profile_end()
-    print("total %.4f ms | " % sum(r["ms"] for r in recs) + " ".join("%s %.4f" % (r["name"][:12], r["ms"]) for r in recs[:14]))
+    print("total %.4f ms | " % sum(r["ms"] for r in recs) + " ".join("%s %.4f" % (r["name"][:12], r["ms"]) for r in recs[:int(os.environ.get("LT_MAX", "14"))]))
