@@ -64,6 +64,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   constexpr int NQ = (NTAPS + 3) / 4;    // macro steps (groups of four taps) per channel block
   constexpr int NGRP = v2_groups(NTAPS), V2_DA_BYTES = v2_slab_bytes(NTAPS);
   constexpr int NSLOT = 2;               // fragment slots per phase: tile g + 1 is read while tile g multiplies
+  constexpr int RING = NTAPS == 5 ? 3 : 2;   // slab buffers (5 taps: a macro step spans two channel blocks, both stay resident)
   const int tid = threadIdx.x;
   int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,19 +99,22 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * V2_DA_BYTES + g * 1024);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory");
   };
+  auto buf_of = [&](int cb) __attribute__((always_inline)) { return RING == 3 ? cb % 3 : cb & 1; };
   auto dma_next = [&](int cb) __attribute__((always_inline)) {  // slab cb + 1: five pieces per wave (17 groups, the last ones duplicates)
     const int nx = cb + 1;
     const int l = lane_now();
+    const int nb_ = buf_of(nx);
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int g = wave + 4 * i;
-      dma_a(nx, (cb + 1) & 1, g < NGRP ? g : NGRP - 1, l);
+      dma_a(nx, nb_, g < NGRP ? g : NGRP - 1, l);
     }
   };
   // weights of this wave's 32-channel block: uniform bases (scalar registers) + one lane offset each
   const int nb = (n0 >> 5) + wave;
   const char* Wm = reinterpret_cast<const char*>(p.Wfr) + (int64_t)nb * ncb * (8 * NQ) * kMainCt;     // [cb][4 NQ taps][2 tiles][1 KB]
-  const char* Wx = reinterpret_cast<const char*>(p.Wx6) + (int64_t)nb * ncb * (4 * NQ) * kXCt;        // [cb][q][term][2 tiles][2 KB]
+  // cross weights: [cb][q][term][2 tiles][2 KB]; 5 taps: [pair of channel blocks][3 macro steps][term][2 tiles][2 KB]
+  const char* Wx = reinterpret_cast<const char*>(p.Wx6) + (NTAPS == 5 ? (int64_t)nb * (ncb >> 1) * 12 * kXCt : (int64_t)nb * ncb * (4 * NQ) * kXCt);
   auto load_w2 = [&](WSet& W, int cb, int tap0) __attribute__((always_inline)) {
     const int voA = lane_now() << 4;
     const char* b = Wm + ((int64_t)cb * (8 * NQ) + tap0 * 2) * kMainCt;
@@ -122,9 +126,9 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     const char* b = Wm + ((int64_t)cb * (8 * NQ) + tap0 * 2) * kMainCt;
     V2_GLD16(W.w[0][0], voA, b, 0); V2_GLD16(W.w[0][1], voA, b, 1024);
   };
-  auto load_x = [&](XSet& X, int cb, int q, int term) __attribute__((always_inline)) {
+  auto load_x = [&](XSet& X, int cb, int q, int term) __attribute__((always_inline)) {       // (5 taps: cb = the pair's index, q < 3)
     const int voA = lane_now() << 4;
-    const char* b = Wx + ((((int64_t)cb * NQ + q) * 2 + term) * 2) * kXCt;
+    const char* b = Wx + ((((int64_t)cb * (NTAPS == 5 ? 3 : NQ) + q) * 2 + term) * 2) * kXCt;
     V2_GLD16(X.c[0], voA, b, 0); V2_GLD16(X.t[0], voA, b, 1024);
     V2_GLD16(X.c[1], voA, b, 2048); V2_GLD16(X.t[1], voA, b, 3072);
   };
@@ -149,10 +153,16 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     return rx * V2_DROW + ((4 ^ sx) << 4);
   };
 
-  // ---- a cross sub-phase: term 0 = w_lo6 x a_hi6 (chunks 4, 6), term 1 = w_hi6 x a_lo6 (chunks 5, 7); 16 scaled MFMAs
-  auto x_phase = [&](const XSet& X, int cb, int q, int term) __attribute__((always_inline)) {
-    const char* slab = smem + (cb & 1) * V2_DA_BYTES;
-    const int ob = cross_off(lane_now(), q);
+  // (row c16 + tap of slab buffer `b`, as an offset from the start of the LDS: the buffer bases have bits 4, 5 clear)
+  auto cross_at = [&](int l, int base, int tap) __attribute__((always_inline)) {      // base = byte offset of the slab buffer
+    const int rx = (l & 15) + tap, px = rx >> 1;
+    const int sx = (((px >> 1) & 1) << 2) | (((px >> 2) & 1) << 1) | (px & 1);
+    return base + rx * V2_DROW + ((4 ^ sx) << 4);
+  };
+  // ---- a cross sub-phase: term 0 = w_lo6 x a_hi6 (chunks 4, 6), term 1 = w_hi6 x a_lo6 (chunks 5, 7); 16 scaled MFMAs;
+  //      ob = this lane's K group: LDS offset of chunk 4 of its row in tile 0
+  auto x_phase_ob = [&](const XSet& X, int ob, int term) __attribute__((always_inline)) {
+    const char* slab = smem;
     const int oc = ob ^ (term << 4), ot = ob ^ (32 | (term << 4));
     v4i fc[NSLOT], ft[NSLOT];             // codes 0-15; {codes 16-23, scale dword (byte 0 hi, byte 1 lo), pad}: read NSLOT - 1 tiles ahead
     auto rd = [&](int g, int s) __attribute__((always_inline)) {
@@ -175,9 +185,12 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  auto x_phase = [&](const XSet& X, int cb, int q, int term) __attribute__((always_inline)) {
+    x_phase_ob(X, buf_of(cb) * V2_DA_BYTES + cross_off(lane_now(), q), term);
+  };
   // ---- a main phase: hi * hi of taps tap0 .. tap0 + NT - 1 (NT = 1, 2); 16 MFMAs per tap
   auto m_phase = [&](const WSet& W, int cb, int tap0, int nt) __attribute__((always_inline)) {
-    const char* slab = smem + (cb & 1) * V2_DA_BYTES;
+    const char* slab = smem + buf_of(cb) * V2_DA_BYTES;
     int of[2];
     const int l = lane_now();
 #pragma unroll
@@ -207,10 +220,10 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   XSet XA, XB;
   WSet WA, WB;
   // prologue: slab cb_begin; XA, XB = the cross sets of (cb_begin, q 0); 7 taps: WA = taps 0, 1; 5 taps: WB = taps 2, 3
-  for (int g = wave; g < NGRP; g += 4) dma_a(cb_begin, cb_begin & 1, g, lane_now());
-  load_x(XA, cb_begin, 0, 0);
-  load_x(XB, cb_begin, 0, 1);
-  if (NTAPS == 7 || NTAPS == 3) load_w2(WA, cb_begin, 0);
+  for (int g = wave; g < NGRP; g += 4) dma_a(cb_begin, buf_of(cb_begin), g, lane_now());
+  load_x(XA, NTAPS == 5 ? cb_begin >> 1 : cb_begin, 0, 0);
+  load_x(XB, NTAPS == 5 ? cb_begin >> 1 : cb_begin, 0, 1);
+  if (NTAPS == 7 || NTAPS == 3 || NTAPS == 5) load_w2(WA, cb_begin, 0);
   else load_w2(WB, cb_begin, 2);           // (5 and 9 taps issue WA = taps 0, 1 at the top of the channel block)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -219,8 +232,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   // the operations issued behind the set it releases:
   //   7 taps  XA0: slab x5, WB(2,3) x4 | XB0: XA(q1) x4 | M01: XB(q1) x4 | M23: WA(4,5) x4 | XA1: WB(6) x2 | XB1: XA(q0') x4 | M45: XB(q0') x4 | M6: WA(0,1)' x4
   //   waits   XA0 8    XB0 13 (8) M01 13 (8) M23 8   XA1 8    XB1 6    M45 6 (2)    M6 8 (0)     (the last one stages no slab either)
-  //   5 taps  XA0: WA(0,1) x4, slab x5 | XB0: XA(q1) x4 | M01: XB(q1) x4 | M23: WA(4) x2 | XA1: WB(2,3)' x4 | XB1: XA(q0') x4 | M4: XB(q0') x4
-  //   waits   XA0 4    XB0 9 (4) M01 9 (4) M23 8    XA1 6    XB1 6 (2)    M4 8 (0)          (in brackets: the last channel block)
+  //   (in brackets: the last channel block; the tables of the 3-, 5- and 9-tap bodies stand at their code)
   // The last channel block issues nothing for a next one, so its final waits count fewer operations: it is a second, straight-line
   // copy of the body behind the loop (a run-time test inside one body splits it into blocks and costs the register allocation).
   auto body = [&](int cb, auto last_tag) __attribute__((always_inline)) {
@@ -325,44 +337,90 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
       __builtin_amdgcn_sched_barrier(0);
       m_phase(WA, cb, 8, 1);
     } else {
+      // 5 taps, a PAIR of channel blocks cb, c1 = cb + 1 per body: the ten taps fill three macro steps (12 K groups) instead of
+      // four (16) -- q0 = taps 0-3 of cb; q1 = tap 4 of cb + taps 0-2 of c1; q2 = taps 3, 4 of c1 + two groups of zero weights (they
+      // read the rows of tap 4 again) -- 128 instead of 144 MFMAs per channel block.  q1 reads both slabs: three slab buffers in a
+      // ring, slab c + 1 still goes out at the top of block c (its buffer held slab c - 2, last read in the block before).
+      //   block A  XA(q0): WB(2,3) x4, slab c1 x5 | XB(q0): XA(q1) x4 | M01: XB(q1) x4 | M23: WA(4) x2 | M4: WB(0,1 c1) x4 | barrier
+      //   block B  XA(q1): WA(2,3 c1) x4, slab x5 | XB(q1): XA(q2) x4 | M01': XB(q2) x4 | M23': WB(4 c1) x2 | XA(q2): WA(0,1)'' x4 |
+      //            XB(q2): XA(q0'') x4 | M4': XB(q0'') x4 | barrier
+      //   waits    A: 4  9  21  8  0      B: 10  15 (10)  13 (8)  8  6  6 (2)  8 (0)       (in brackets: the last pair)
+      const int c1 = cb + 1, k = cb >> 1;
+      // K groups of the three macro steps (selects, not branches: a branch here would split the body into blocks)
+      auto ob0 = [&]() __attribute__((always_inline)) {
+        const int l = lane_now();
+        return cross_at(l, buf_of(cb) * V2_DA_BYTES, l >> 4);
+      };
+      auto ob1 = [&]() __attribute__((always_inline)) {       // group 0: tap 4 of cb; groups 1-3: taps 0-2 of c1
+        const int l = lane_now(), g = l >> 4;
+        const int b0 = buf_of(cb) * V2_DA_BYTES, b1 = buf_of(c1) * V2_DA_BYTES;
+        return cross_at(l, g == 0 ? b0 : b1, g == 0 ? 4 : g - 1);
+      };
+      auto ob2 = [&]() __attribute__((always_inline)) {       // groups 0, 1: taps 3, 4 of c1; groups 2, 3 (zero weights): tap 4 again
+        const int l = lane_now(), g = l >> 4;
+        return cross_at(l, buf_of(c1) * V2_DA_BYTES, g == 0 ? 3 : 4);
+      };
       V2_WAITX(4, XA);
-      load_w2(WA, cb, 0);                 // (the one set with a single macro step of lead: its registers serve tap 4 until the end of
-                                          //  the channel block before; two cross sub-phases = 32 MFMAs of this wave, ~1.5 k cycles in wall time)
-      if constexpr (!last) dma_next(cb);
+      load_w2(WB, cb, 2);
+      dma_next(cb);
       __builtin_amdgcn_sched_barrier(0);
-      x_phase(XA, cb, 0, 0);
-      if constexpr (!last) V2_WAITX(9, XB); else V2_WAITX(4, XB);
-      load_x(XA, cb, 1, 0);
+      x_phase_ob(XA, ob0(), 0);
+      V2_WAITX(9, XB);
+      load_x(XA, k, 1, 0);
       __builtin_amdgcn_sched_barrier(0);
-      x_phase(XB, cb, 0, 1);
-      if constexpr (!last) V2_WAITW2(9, WA); else V2_WAITW2(4, WA);
-      load_x(XB, cb, 1, 1);
+      x_phase_ob(XB, ob0(), 1);
+      V2_WAITW2(21, WA);
+      load_x(XB, k, 1, 1);
       __builtin_amdgcn_sched_barrier(0);
       m_phase(WA, cb, 0, 2);
-      V2_WAITW2(8, WB);
+      V2_WAITW2(8, WB);                   // (13 would do for WB; 8 also lands slab c1 before the barrier)
       load_w1(WA, cb, 4);
       __builtin_amdgcn_sched_barrier(0);
       m_phase(WB, cb, 2, 2);
-      V2_WAITX(6, XA);
-      if constexpr (!last) load_w2(WB, nx, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XA, cb, 1, 0);
-      if constexpr (!last) { V2_WAITX(6, XB); load_x(XA, nx, 0, 0); } else { V2_WAITX(2, XB); }
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XB, cb, 1, 1);
-      if constexpr (!last) { V2_WAITW1(8, WA); load_x(XB, nx, 0, 1); } else { V2_WAITW1(0, WA); }
+      V2_WAITW1(0, WA);                   // (tap 4: one main phase of lead, as in the per-block schedule)
+      load_w2(WB, c1, 0);
       __builtin_amdgcn_sched_barrier(0);
       m_phase(WA, cb, 4, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                    // slab c1 is visible; (slab cb stays: q1 reads its tap 4)
+      V2_WAITX(10, XA);
+      load_w2(WA, c1, 2);
+      if constexpr (!last) dma_next(c1);
+      __builtin_amdgcn_sched_barrier(0);
+      x_phase_ob(XA, ob1(), 0);
+      if constexpr (!last) V2_WAITX(15, XB); else V2_WAITX(10, XB);
+      load_x(XA, k, 2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      x_phase_ob(XB, ob1(), 1);
+      if constexpr (!last) V2_WAITW2(13, WB); else V2_WAITW2(8, WB);
+      load_x(XB, k, 2, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      m_phase(WB, c1, 0, 2);
+      V2_WAITW2(8, WA);
+      load_w1(WB, c1, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      m_phase(WA, c1, 2, 2);
+      V2_WAITX(6, XA);
+      if constexpr (!last) load_w2(WA, cb + 2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      x_phase_ob(XA, ob2(), 0);
+      if constexpr (!last) { V2_WAITX(6, XB); load_x(XA, k + 1, 0, 0); } else { V2_WAITX(2, XB); }
+      __builtin_amdgcn_sched_barrier(0);
+      x_phase_ob(XB, ob2(), 1);
+      if constexpr (!last) { V2_WAITW1(8, WB); load_x(XB, k + 1, 0, 1); } else { V2_WAITW1(0, WB); }
+      __builtin_amdgcn_sched_barrier(0);
+      m_phase(WB, c1, 4, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                      // every wave is done reading slab cb; slab cb + 1 landed long ago (waits above)
   };
-  for (int cb = cb_begin; cb + 1 < cb_end; ++cb) body(cb, std::false_type());
+  constexpr int CBS = NTAPS == 5 ? 2 : 1;          // channel blocks per body
+  for (int cb = cb_begin; cb + CBS < cb_end; cb += CBS) body(cb, std::false_type());
   // (hand-over to the straight-line copy: an empty asm over the accumulators ends their live ranges here, so that the allocator may
   // re-assign them for the copy instead of spilling one tile across the seam -- it did, in the 5-tap form)
 #pragma unroll
   for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(acc[g][0]), "+v"(acc[g][1]));
-  body(cb_end - 1, std::true_type());
+  body(cb_end - CBS, std::true_type());
   // (nothing is in flight here: the last body waited for its last set with vmcnt(0) and its end-of-block barrier has been passed
   // by every wave, so the slab buffers may become the epilogue's scratch)
   __syncthreads();
@@ -528,7 +586,7 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   static std::mutex mu;
   static bool attr_set[64] = {};
-  const size_t smem = (size_t)2 * v2_slab_bytes(taps);
+  const size_t smem = (size_t)(taps == 5 ? 3 : 2) * v2_slab_bytes(taps);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   {
@@ -539,14 +597,16 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
                           reinterpret_cast<const void*>(gemm_f6v2_kernel<9, false>), reinterpret_cast<const void*>(gemm_f6v2_kernel<9, true>),
                           reinterpret_cast<const void*>(gemm_f6v2_kernel<3, true>), reinterpret_cast<const void*>(gemm_f6v2_kernel<3, true, true>)};
       for (const void* k : ks) {
-        const hipError_t r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * v2_slab_bytes(9));
+        const hipError_t r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * v2_slab_bytes(5));
         if (r != hipSuccess) return r;
       }
       attr_set[dev & 63] = true;
     }
   }
   const int nMt = ((a.M + V2_BM - 1) / V2_BM) * (bins ? a.nbin : 1), nNt = a.Npad / V2_BN, ncb = a.cin >> 5;
-  const bool tail = !bins && a.tail_mt > 0 && (a.ksplit == 2 || a.ksplit == 4 || a.ksplit == 8) && a.partial && a.tail_mt < nMt && ncb % a.ksplit == 0;
+  if (taps == 5 && (ncb & 1)) return hipErrorInvalidValue;      // the 5-tap body takes channel blocks in pairs
+  const bool tail = !bins && a.tail_mt > 0 && (a.ksplit == 2 || a.ksplit == 4 || a.ksplit == 8) && a.partial && a.tail_mt < nMt && ncb % a.ksplit == 0 &&
+                    (taps != 5 || (ncb / a.ksplit) % 2 == 0);
   const int nMain = tail ? nMt - a.tail_mt : nMt;
   const int S = tail ? a.ksplit : 0;
   const dim3 grid(nMain * nNt + (tail ? a.tail_mt * nNt * a.ksplit : 0)), block(256);

@@ -813,7 +813,11 @@ int upload_layer(xv_handle* h, Layer& L) {
       const int fw = L.mode == 1 ? 3 : L.w, fcin = L.mode == 1 ? 3 * L.cin : L.cin;
       const int ncb = fcin / 32, NQ = (fw + 3) / 4;
       const size_t main_ct = 64 * 16, cross_ct = 2 * 64 * 16;
-      std::vector<unsigned char> wm((size_t)(L.Npad / 32) * ncb * (4 * NQ) * 2 * main_ct, 0), wx((size_t)(L.Npad / 32) * ncb * NQ * 2 * 2 * cross_ct, 0);
+      // 5 taps: the cross operands are grouped over PAIRS of channel blocks -- slot p = 4 q + g (macro step q < 3, K group g) of pair k
+      // is tap p % 5 of channel block 2 k + p / 5 for p < 10, zero weights for p = 10, 11:  [Npad/32][cin/64][3][2 terms][2 tiles]
+      const bool pairs = L.mode == 0 && fw == 5;
+      const size_t xsteps = pairs ? (size_t)(ncb / 2) * 3 : (size_t)ncb * NQ;
+      std::vector<unsigned char> wm((size_t)(L.Npad / 32) * ncb * (4 * NQ) * 2 * main_ct, 0), wx((size_t)(L.Npad / 32) * xsteps * 2 * 2 * cross_ct, 0);
       for (int n = 0; n < L.Npad; ++n) {
         const int nb = n >> 5, ct = (n >> 4) & 1, r16 = n & 15;
         for (int cb = 0; cb < ncb; ++cb)
@@ -828,9 +832,16 @@ int upload_layer(xv_handle* h, Layer& L) {
             }
             unsigned char* pm = &wm[((((size_t)nb * ncb + cb) * (4 * NQ) + j) * 2 + ct) * main_ct];
             for (int kc = 0; kc < 4; ++kc) memcpy(pm + (16 * kc + r16) * 16, &hh[8 * kc], 16);
-            const int ln = 16 * (j & 3) + r16;
+            int slot = j;                                   // position among the K groups: macro step slot >> 2, group slot & 3
+            size_t xstep = (size_t)cb * NQ + (j >> 2);
+            if (pairs) {
+              if (j >= fw) continue;                        // (the two zero groups of a pair stay zero)
+              slot = (cb & 1) * 5 + j;
+              xstep = (size_t)(cb >> 1) * 3 + (slot >> 2);
+            }
+            const int ln = 16 * (slot & 3) + r16;
             for (int term = 0; term < 2; ++term) {          // term 0 multiplies q6(hi) of the activations, term 1 q6(lo)
-              unsigned char* px = &wx[((((((size_t)nb * ncb + cb) * NQ + (j >> 2)) * 2 + term) * 2) + ct) * cross_ct];
+              unsigned char* px = &wx[(((((size_t)nb * xsteps + xstep) * 2 + term) * 2) + ct) * cross_ct];
               unsigned char c24[24], sc;
               host_quant32(term == 0 ? wlo : whi, c24, &sc);
               memcpy(px + ln * 16, c24, 16);
@@ -957,7 +968,7 @@ int xv_finalize(xv_handle* h) {
       // two-unit split: the 5-, 7- and 9-tap layers over whole 32-channel blocks (the first layer, K = 5 x 30, stays on the f16 kernel and writes
       // the block format of its reader: gemm_bf16x3_w14p2_kernel<1, 3, true>)
       L.use_f6 = h->desc.precision == XV_PREC_F16F6 && L.use_split && !L.im2col && (L.w == 5 || L.w == 7 || L.w == 9) &&
-                 L.cin % 32 == 0 && L.cout % 4 == 0;
+                 L.cin % (L.w == 5 ? 64 : 32) == 0 && L.cout % 4 == 0;      // (5 taps: channel blocks in pairs)
     } else {      // grid convolutions: whole SB blocks per tap; conv0 goes through its own im2col
       L.use_split = bf && (L.mode == 4 || L.cin % 32 == 0);
       // two-unit split of the stride-1 3 x 3 convolutions: three taps along time over the 3 C channels of a kernel row
