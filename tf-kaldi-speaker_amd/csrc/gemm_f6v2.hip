@@ -50,6 +50,43 @@ struct XSet { v4i c[2]; v4i t[2]; };               // per channel tile: bytes 0-
                                                    // two halves of one 8-register operand tuple (the scaled MFMA reads the first six)
 struct WSet { f16x8 w[2][2]; };                    // [tap of the pair][channel tile]
 
+// The three-tap (ResNet) form runs a QUAD of channel blocks per loop body: twelve (block, tap) pairs fill three macro steps of the
+// cross terms exactly (one macro step per block would carry a zero K group: 80 MFMAs per block instead of 72).  Sixteen phases, each
+// with its own register set, in a fixed rotation of four sets: the set a phase has just consumed is reloaded, at the start of the
+// next phase, for the phase three further on -- so every load has three phases (48 - 96 MFMAs of this wave) to land, and every wait
+// count follows from the table below (v2q_wait).  kind 0 = hi * hi of `b` taps from tap `a` of block `blk`; kind 1 = cross term
+// `b` of macro step `a`, run in the block whose slab completes its K groups (step q covers pairs 4 q .. 4 q + 3 = blocks
+// (4 q) / 3 .. (4 q + 3) / 3; both slabs are resident: ring of three buffers).  Two two-tap phases are split into single taps so
+// that the phase count is a multiple of the four sets.
+struct V2Phase { int kind, blk, a, b; };
+constexpr V2Phase kQuad[16] = {{0, 0, 0, 2}, {0, 0, 2, 1},
+                               {1, 1, 0, 0}, {1, 1, 0, 1}, {0, 1, 0, 2}, {0, 1, 2, 1},
+                               {1, 2, 1, 0}, {1, 2, 1, 1}, {0, 2, 0, 1}, {0, 2, 1, 1}, {0, 2, 2, 1},
+                               {1, 3, 2, 0}, {1, 3, 2, 1}, {0, 3, 0, 1}, {0, 3, 1, 1}, {0, 3, 2, 1}};
+constexpr int v2q_loads(int i) { return kQuad[i & 15].kind == 1 ? 4 : 2 * kQuad[i & 15].b; }
+constexpr bool v2q_first(int i) { return (i & 15) == 0 || kQuad[i & 15].blk != kQuad[(i & 15) - 1].blk; }
+constexpr bool v2q_end(int i) { return (i & 15) == 15 || kQuad[i & 15].blk != kQuad[(i & 15) + 1].blk; }
+// does phase j (relative to this quad; negative = the quad before, which is never the last) issue a set / a slab?
+constexpr bool v2q_has_set(int j, bool last) { return j + 3 < 16 || !last; }
+constexpr bool v2q_has_slab(int j, bool last) { return v2q_first(j + 16) && (j < 0 || !(last && kQuad[j].blk == 3)); }
+// operations in flight behind the set of phase i when it is awaited: the issues of phases i - 3 (its slab only), i - 2, i - 1,
+// each "set for the phase three on, then the slab of the next block if the phase opens a block"
+constexpr int v2q_wait(int i, bool last) {
+  int n = 0;
+  for (int j = i - 3; j <= i - 1; ++j) {
+    if (j != i - 3 && v2q_has_set(j, last)) n += v2q_loads(j + 3 + 16);
+    if (v2q_has_slab(j, last)) n += 5;
+  }
+  return n;
+}
+// before the barrier that ends a block: everything issued behind its slab = the sets issued by its later phases
+constexpr int v2q_wait_slab(int iend, bool last) {
+  int n = 0;
+  for (int j = iend; j >= 0 && !v2q_first(j); --j)
+    if (v2q_has_set(j, last)) n += v2q_loads(j + 3);
+  return n;
+}
+
 }  // namespace
 
 #define V2_GLD16(dst, voff, sbase, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(dst) : "v"(voff), "s"(sbase))
@@ -64,7 +101,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   constexpr int NQ = (NTAPS + 3) / 4;    // macro steps (groups of four taps) per channel block
   constexpr int NGRP = v2_groups(NTAPS), V2_DA_BYTES = v2_slab_bytes(NTAPS);
   constexpr int NSLOT = 2;               // fragment slots per phase: tile g + 1 is read while tile g multiplies
-  constexpr int RING = NTAPS == 5 ? 3 : 2;   // slab buffers (5 taps: a macro step spans two channel blocks, both stay resident)
+  constexpr int RING = (NTAPS == 5 || NTAPS == 3) ? 3 : 2;   // slab buffers (3, 5 taps: a macro step spans two channel blocks, both stay resident)
   const int tid = threadIdx.x;
   int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,7 +151,9 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   const int nb = (n0 >> 5) + wave;
   const char* Wm = reinterpret_cast<const char*>(p.Wfr) + (int64_t)nb * ncb * (8 * NQ) * kMainCt;     // [cb][4 NQ taps][2 tiles][1 KB]
   // cross weights: [cb][q][term][2 tiles][2 KB]; 5 taps: [pair of channel blocks][3 macro steps][term][2 tiles][2 KB]
-  const char* Wx = reinterpret_cast<const char*>(p.Wx6) + (NTAPS == 5 ? (int64_t)nb * (ncb >> 1) * 12 * kXCt : (int64_t)nb * ncb * (4 * NQ) * kXCt);
+  //                3 taps: [quad of channel blocks][3 macro steps][term][2 tiles][2 KB]
+  const char* Wx = reinterpret_cast<const char*>(p.Wx6) + (NTAPS == 5 ? (int64_t)nb * (ncb >> 1) * 12 * kXCt
+                                                            : NTAPS == 3 ? (int64_t)nb * (ncb >> 2) * 12 * kXCt : (int64_t)nb * ncb * (4 * NQ) * kXCt);
   auto load_w2 = [&](WSet& W, int cb, int tap0) __attribute__((always_inline)) {
     const int voA = lane_now() << 4;
     const char* b = Wm + ((int64_t)cb * (8 * NQ) + tap0 * 2) * kMainCt;
@@ -217,13 +256,132 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     }
   };
 
+  if constexpr (NTAPS == 3) {
+    // ---- the ResNet form (3 x 3 on the zero-bordered grid = three taps along time over the 3 C channels of a kernel row): quads of
+    //      channel blocks on the sixteen-phase rotation described at kQuad
+    struct RSet { v4i r[4]; };             // a cross set {codes 0-15, tail | scale} x 2 channel tiles, or main weights [tap][tile]
+    RSet S[4];
+    auto load_set = [&](RSet& R, int cbq, auto idx) __attribute__((always_inline)) {   // the set of phase idx of the quad at cbq
+      constexpr V2Phase ph = kQuad[decltype(idx)::value & 15];
+      const int voA = lane_now() << 4;
+      if constexpr (ph.kind == 1) {
+        const char* b = Wx + ((((int64_t)(cbq >> 2) * 3 + ph.a) * 2 + ph.b) * 2) * kXCt;
+        V2_GLD16(R.r[0], voA, b, 0); V2_GLD16(R.r[1], voA, b, 1024);
+        V2_GLD16(R.r[2], voA, b, 2048); V2_GLD16(R.r[3], voA, b, 3072);
+      } else {
+        const char* b = Wm + ((int64_t)(cbq + ph.blk) * (8 * NQ) + ph.a * 2) * kMainCt;
+        V2_GLD16(R.r[0], voA, b, 0); V2_GLD16(R.r[1], voA, b, 1024);
+        if constexpr (ph.b == 2) { V2_GLD16(R.r[2], voA, b, 2048); V2_GLD16(R.r[3], voA, b, 3072); }
+      }
+    };
+    auto x_phase_s = [&](const RSet& X, int ob, int term) __attribute__((always_inline)) {
+      const int oc = ob ^ (term << 4), ot = ob ^ (32 | (term << 4));
+      v4i fc[NSLOT], ft[NSLOT];
+      auto rd = [&](int g, int s) __attribute__((always_inline)) {
+        fc[s] = *reinterpret_cast<const v4i*>(smem + oc + g * 2048);
+        ft[s] = *reinterpret_cast<const v4i*>(smem + ot + g * 2048);
+      };
+#pragma unroll
+      for (int g = 0; g < NSLOT - 1; ++g) rd(g, g);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int s = g % NSLOT;
+        if (g + NSLOT - 1 < 8) rd(g + NSLOT - 1, (g + NSLOT - 1) % NSLOT);
+        const v8i b = __builtin_shufflevector(fc[s], ft[s], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const v8i wa = __builtin_shufflevector(X.r[2 * c], X.r[2 * c + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+          if (term == 0) acc[g][c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, b, acc[g][c], 2, 2, 0, X.r[2 * c + 1][2], 0, ft[s][2]);
+          else           acc[g][c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, b, acc[g][c], 2, 2, 0, X.r[2 * c + 1][2], 1, ft[s][2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto m_phase_s = [&](const RSet& W, int cb, int tap0, int nt) __attribute__((always_inline)) {
+      const char* slab = smem + buf_of(cb) * V2_DA_BYTES;
+      int of[2];
+      const int l = lane_now();
+#pragma unroll
+      for (int j = 0; j < 2; ++j) of[j] = j < nt ? main_off(l, tap0 + j) : 0;
+      f16x8 fm[NSLOT][2];
+      auto rd = [&](int g, int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (j < nt) fm[s][j] = *reinterpret_cast<const f16x8*>(slab + of[j] + g * 2048);
+      };
+#pragma unroll
+      for (int g = 0; g < NSLOT - 1; ++g) rd(g, g);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int s = g % NSLOT;
+        if (g + NSLOT - 1 < 8) rd(g + NSLOT - 1, (g + NSLOT - 1) % NSLOT);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (j < nt) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+              acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W.r[2 * j + c]), fm[s][j], acc[g][c], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // K groups of macro step q (in block q + 1 of the quad at cbq): pair 4 q + g = block (4 q + g) / 3, tap (4 q + g) % 3 -- two
+    // neighbouring blocks, chosen by a select
+    auto ob_of = [&](int cbq, int q) __attribute__((always_inline)) {
+      const int l = lane_now(), pr = 4 * q + (l >> 4);
+      const int lo = (4 * q) / 3;
+      const int hi_sel = pr >= 3 * (lo + 1);
+      const int tap = pr - 3 * (lo + hi_sel);
+      const int b_lo = buf_of(cbq + lo) * V2_DA_BYTES, b_hi = buf_of(cbq + lo + 1) * V2_DA_BYTES;
+      return cross_at(l, hi_sel ? b_hi : b_lo, tap);
+    };
+    // prologue: slab cb_begin, the sets of phases 0, 1, 2
+    for (int g = wave; g < NGRP; g += 4) dma_a(cb_begin, buf_of(cb_begin), g, lane_now());
+    load_set(S[0], cb_begin, std::integral_constant<int, 0>());
+    load_set(S[1], cb_begin, std::integral_constant<int, 1>());
+    load_set(S[2], cb_begin, std::integral_constant<int, 2>());
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto quad = [&](int cbq, auto last_tag) __attribute__((always_inline)) {
+      constexpr bool last = decltype(last_tag)::value;
+      auto phase = [&](auto idx) __attribute__((always_inline)) {
+        constexpr int i = decltype(idx)::value;
+        constexpr V2Phase ph = kQuad[i];
+        RSet& R = S[i & 3];
+        if constexpr (ph.kind == 0 && ph.b == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(R.r[0]), "+v"(R.r[1]) : "n"(v2q_wait(i, last)));
+        else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(R.r[0]), "+v"(R.r[1]), "+v"(R.r[2]), "+v"(R.r[3]) : "n"(v2q_wait(i, last)));
+        if constexpr (v2q_has_set(i, last)) load_set(S[(i + 3) & 3], i + 3 < 16 ? cbq : cbq + 4, std::integral_constant<int, (i + 3) & 15>());
+        if constexpr (v2q_has_slab(i, last)) dma_next(cbq + ph.blk);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ph.kind == 1) x_phase_s(R, ob_of(cbq, ph.a), ph.b);
+        else m_phase_s(R, cbq + ph.blk, ph.a, ph.b);
+        if constexpr (v2q_end(i)) {
+          // the block's slab pieces (issued by its first phase) have landed before the barrier hands the buffer over
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(v2q_wait_slab(i, last)) : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          __syncthreads();                // every wave is done with the slab two blocks back; the next one is visible
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      phase(std::integral_constant<int, 0>()); phase(std::integral_constant<int, 1>()); phase(std::integral_constant<int, 2>());
+      phase(std::integral_constant<int, 3>()); phase(std::integral_constant<int, 4>()); phase(std::integral_constant<int, 5>());
+      phase(std::integral_constant<int, 6>()); phase(std::integral_constant<int, 7>()); phase(std::integral_constant<int, 8>());
+      phase(std::integral_constant<int, 9>()); phase(std::integral_constant<int, 10>()); phase(std::integral_constant<int, 11>());
+      phase(std::integral_constant<int, 12>()); phase(std::integral_constant<int, 13>()); phase(std::integral_constant<int, 14>());
+      phase(std::integral_constant<int, 15>());
+    };
+    for (int cb = cb_begin; cb + 4 < cb_end; cb += 4) quad(cb, std::false_type());
+#pragma unroll
+    for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(acc[g][0]), "+v"(acc[g][1]));
+    quad(cb_end - 4, std::true_type());
+  } else {
   XSet XA, XB;
   WSet WA, WB;
   // prologue: slab cb_begin; XA, XB = the cross sets of (cb_begin, q 0); 7 taps: WA = taps 0, 1; 5 taps: WB = taps 2, 3
   for (int g = wave; g < NGRP; g += 4) dma_a(cb_begin, buf_of(cb_begin), g, lane_now());
   load_x(XA, NTAPS == 5 ? cb_begin >> 1 : cb_begin, 0, 0);
   load_x(XB, NTAPS == 5 ? cb_begin >> 1 : cb_begin, 0, 1);
-  if (NTAPS == 7 || NTAPS == 3 || NTAPS == 5) load_w2(WA, cb_begin, 0);
+  if (NTAPS == 7 || NTAPS == 5) load_w2(WA, cb_begin, 0);
   else load_w2(WB, cb_begin, 2);           // (5 and 9 taps issue WA = taps 0, 1 at the top of the channel block)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -238,26 +396,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   auto body = [&](int cb, auto last_tag) __attribute__((always_inline)) {
     constexpr bool last = decltype(last_tag)::value;
     const int nx = cb + 1;
-    if constexpr (NTAPS == 3) {
-      // The 3 x 3 convolutions of the ResNet stages as a three-tap convolution along time over 3 C channels (the three frequency
-      // taps of a kernel row are one contiguous run of the zero-bordered grid: csrc/grid.hip).  One macro step per channel block:
-      //   3 taps  XA0: WB(2) x2, slab x5 | XB0: XA' x4 | M01: XB' x4 | M2: WA(0,1)' x4
-      //   waits   XA0 8    XB0 11 (6)    M01 11 (2)    M2 8 (0)      (M2: 13 would do for WB; 8 also lands the slab before the barrier)
-      V2_WAITX(8, XA);
-      load_w1(WB, cb, 2);
-      if constexpr (!last) dma_next(cb);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XA, cb, 0, 0);
-      if constexpr (!last) { V2_WAITX(11, XB); load_x(XA, nx, 0, 0); } else { V2_WAITX(6, XB); }
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XB, cb, 0, 1);
-      if constexpr (!last) { V2_WAITW2(11, WA); load_x(XB, nx, 0, 1); } else { V2_WAITW2(2, WA); }
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WA, cb, 0, 2);
-      if constexpr (!last) { V2_WAITW1(8, WB); load_w2(WA, nx, 0); } else { V2_WAITW1(0, WB); }
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WB, cb, 2, 1);
-    } else if constexpr (NTAPS == 7) {
+    if constexpr (NTAPS == 7) {
       V2_WAITX(8, XA);
       if constexpr (!last) dma_next(cb);
       load_w2(WB, cb, 2);
@@ -421,6 +560,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
 #pragma unroll
   for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(acc[g][0]), "+v"(acc[g][1]));
   body(cb_end - CBS, std::true_type());
+  }
   // (nothing is in flight here: the last body waited for its last set with vmcnt(0) and its end-of-block barrier has been passed
   // by every wave, so the slab buffers may become the epilogue's scratch)
   __syncthreads();
@@ -586,7 +726,7 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   static std::mutex mu;
   static bool attr_set[64] = {};
-  const size_t smem = (size_t)(taps == 5 ? 3 : 2) * v2_slab_bytes(taps);
+  const size_t smem = (size_t)(taps == 5 || taps == 3 ? 3 : 2) * v2_slab_bytes(taps);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   {
@@ -604,7 +744,8 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
     }
   }
   const int nMt = ((a.M + V2_BM - 1) / V2_BM) * (bins ? a.nbin : 1), nNt = a.Npad / V2_BN, ncb = a.cin >> 5;
-  if (taps == 5 && (ncb & 1)) return hipErrorInvalidValue;      // the 5-tap body takes channel blocks in pairs
+  if (taps == 5 && (ncb & 1)) return hipErrorInvalidValue;      // the 5-tap body takes channel blocks in pairs,
+  if (taps == 3 && (ncb & 3)) return hipErrorInvalidValue;      // the 3-tap body in quads
   const bool tail = !bins && a.tail_mt > 0 && (a.ksplit == 2 || a.ksplit == 4 || a.ksplit == 8) && a.partial && a.tail_mt < nMt && ncb % a.ksplit == 0 &&
                     (taps != 5 || (ncb / a.ksplit) % 2 == 0);
   const int nMain = tail ? nMt - a.tail_mt : nMt;

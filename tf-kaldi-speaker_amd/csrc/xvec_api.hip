@@ -815,8 +815,9 @@ int upload_layer(xv_handle* h, Layer& L) {
       const size_t main_ct = 64 * 16, cross_ct = 2 * 64 * 16;
       // 5 taps: the cross operands are grouped over PAIRS of channel blocks -- slot p = 4 q + g (macro step q < 3, K group g) of pair k
       // is tap p % 5 of channel block 2 k + p / 5 for p < 10, zero weights for p = 10, 11:  [Npad/32][cin/64][3][2 terms][2 tiles]
-      const bool pairs = L.mode == 0 && fw == 5;
-      const size_t xsteps = pairs ? (size_t)(ncb / 2) * 3 : (size_t)ncb * NQ;
+      // 3 taps (ResNet form): over QUADS of channel blocks -- slot p = 3 (cb & 3) + tap, twelve slots = three macro steps exactly
+      const bool pairs = L.mode == 0 && fw == 5, quads = L.mode == 1;
+      const size_t xsteps = pairs ? (size_t)(ncb / 2) * 3 : quads ? (size_t)(ncb / 4) * 3 : (size_t)ncb * NQ;
       std::vector<unsigned char> wm((size_t)(L.Npad / 32) * ncb * (4 * NQ) * 2 * main_ct, 0), wx((size_t)(L.Npad / 32) * xsteps * 2 * 2 * cross_ct, 0);
       for (int n = 0; n < L.Npad; ++n) {
         const int nb = n >> 5, ct = (n >> 4) & 1, r16 = n & 15;
@@ -838,6 +839,10 @@ int upload_layer(xv_handle* h, Layer& L) {
               if (j >= fw) continue;                        // (the two zero groups of a pair stay zero)
               slot = (cb & 1) * 5 + j;
               xstep = (size_t)(cb >> 1) * 3 + (slot >> 2);
+            } else if (quads) {
+              if (j >= fw) continue;
+              slot = (cb & 3) * 3 + j;
+              xstep = (size_t)(cb >> 2) * 3 + (slot >> 2);
             }
             const int ln = 16 * (slot & 3) + r16;
             for (int term = 0; term < 2; ++term) {          // term 0 multiplies q6(hi) of the activations, term 1 q6(lo)
@@ -974,7 +979,7 @@ int xv_finalize(xv_handle* h) {
       // two-unit split of the stride-1 3 x 3 convolutions: three taps along time over the 3 C channels of a kernel row
       // (gemm_f6v2_kernel<3, ...>); whole 128-channel tiles only (stage 1 of the default net, 64 channels, is HBM-bound anyway)
       L.use_f6 = h->desc.precision == XV_PREC_F16F6 && h->opt_grid_f6 && L.mode == 1 && L.use_split && L.sw == 1 && L.st == 1 &&
-                 L.cin % 32 == 0 && L.cout % 128 == 0;
+                 L.cin % 128 == 0 && L.cout % 128 == 0;      // (3 cin / 32 channel blocks, taken in quads)
     }
   }
   if (h->desc.precision == XV_PREC_F16X3 || h->desc.precision == XV_PREC_F16F6) {
