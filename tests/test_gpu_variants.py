@@ -233,7 +233,7 @@ def test_compact_grid_rows_are_bit_identical_to_the_full_enumeration(kw):
             assert np.array_equal(a[node], a2[node]), (kw, prec, node, "second forward")
 
 
-@pytest.mark.parametrize("net", ["tdnn", "tdnn_narrow", "etdnn"])
+@pytest.mark.parametrize("net", ["tdnn", "tdnn_narrow", "tdnn_128", "etdnn"])
 def test_f16f6_two_unit_split(net):
     """XV_PREC_F16F6: the 5-, 7- and 9-tap convolutions compute hi*hi in fp16 and the two cross terms on the block-scaled fp6 path
     (csrc/gemm_f6v2.hip: 1.5 MFMA units per product instead of 3).  tests/analysis/f16f8_error_model.py predicts ~1e-5 on the x-vector;
@@ -245,7 +245,8 @@ def test_f16f6_two_unit_split(net):
     from oracle import ref_numpy
     from tf_kaldi_speaker_amd import synth
     import torch
-    ch = 64 if net == "tdnn_narrow" else 512
+    ch = {"tdnn_narrow": 64, "tdnn_128": 128}.get(net, 512)     # 64: one pair of channel blocks for the 5-tap layer, the 7-tap layer (whole
+                                                                  # quads only) stays on f16x3; 128: exactly one pair / one quad = the peeled last body alone
     params = dict(synth.TDNN_STAT_PARAMS)
     if net == "etdnn":                                  # conv1d k = 5, 5, 7, 9 at tdnn1 / 3 / 5 / 7 (model/tdnn.py:343-591)
         params.update(network_type="extended_tdnn", embedding_node="tdnn12_dense")

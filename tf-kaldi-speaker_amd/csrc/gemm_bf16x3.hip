@@ -881,7 +881,7 @@ constexpr int kTraceWgs = 16384;
 }  // namespace
 #endif
 
-int64_t gemm_bf16x3_tail_plan(int M, int Kpad, int Npad, int w, int* tail_mt, int* splits) {
+int64_t gemm_bf16x3_tail_plan(int M, int Kpad, int Npad, int w, int* tail_mt, int* splits, int cb_quant) {
   *tail_mt = 0;
   *splits = 1;
   if (w < 1 || w > 9 || (Kpad >> 5) % w != 0) return 0;          // (switch: xv_set_option "tail_split")
@@ -892,7 +892,7 @@ int64_t gemm_bf16x3_tail_plan(int M, int Kpad, int Npad, int w, int* tail_mt, in
   const int mt = (r + nNt - 1) / nNt;
   int S = 0;
   for (int c = 8; c >= 2; c >>= 1)
-    if (ncb % c == 0 && ncb / c >= 2 && mt * nNt * c <= 256) { S = c; break; }   // about one slice workgroup per CU
+    if (ncb % c == 0 && ncb / c >= 2 && (ncb / c) % cb_quant == 0 && mt * nNt * c <= 256) { S = c; break; }   // about one slice workgroup per CU
   if (S == 0) return 0;
   *tail_mt = mt;
   *splits = S;

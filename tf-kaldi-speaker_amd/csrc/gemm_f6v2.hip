@@ -50,42 +50,63 @@ struct XSet { v4i c[2]; v4i t[2]; };               // per channel tile: bytes 0-
                                                    // two halves of one 8-register operand tuple (the scaled MFMA reads the first six)
 struct WSet { f16x8 w[2][2]; };                    // [tap of the pair][channel tile]
 
-// The three-tap (ResNet) form runs a QUAD of channel blocks per loop body: twelve (block, tap) pairs fill three macro steps of the
-// cross terms exactly (one macro step per block would carry a zero K group: 80 MFMAs per block instead of 72).  Sixteen phases, each
-// with its own register set, in a fixed rotation of four sets: the set a phase has just consumed is reloaded, at the start of the
-// next phase, for the phase three further on -- so every load has three phases (48 - 96 MFMAs of this wave) to land, and every wait
-// count follows from the table below (v2q_wait).  kind 0 = hi * hi of `b` taps from tap `a` of block `blk`; kind 1 = cross term
-// `b` of macro step `a`, run in the block whose slab completes its K groups (step q covers pairs 4 q .. 4 q + 3 = blocks
-// (4 q) / 3 .. (4 q + 3) / 3; both slabs are resident: ring of three buffers).  Two two-tap phases are split into single taps so
-// that the phase count is a multiple of the four sets.
-struct V2Phase { int kind, blk, a, b; };
-constexpr V2Phase kQuad[16] = {{0, 0, 0, 2}, {0, 0, 2, 1},
-                               {1, 1, 0, 0}, {1, 1, 0, 1}, {0, 1, 0, 2}, {0, 1, 2, 1},
-                               {1, 2, 1, 0}, {1, 2, 1, 1}, {0, 2, 0, 1}, {0, 2, 1, 1}, {0, 2, 2, 1},
-                               {1, 3, 2, 0}, {1, 3, 2, 1}, {0, 3, 0, 1}, {0, 3, 1, 1}, {0, 3, 2, 1}};
-constexpr int v2q_loads(int i) { return kQuad[i & 15].kind == 1 ? 4 : 2 * kQuad[i & 15].b; }
-constexpr bool v2q_first(int i) { return (i & 15) == 0 || kQuad[i & 15].blk != kQuad[(i & 15) - 1].blk; }
-constexpr bool v2q_end(int i) { return (i & 15) == 15 || kQuad[i & 15].blk != kQuad[(i & 15) + 1].blk; }
+// Generated schedules.  The 3-tap (ResNet) and the 7-tap form run a QUAD of channel blocks per loop body: 4 T (block, tap) pairs
+// fill T macro steps of the cross terms exactly (one block at a time needs ceil(T / 4) steps of four K groups per block: a zero K
+// group in every block for T = 3 -- 80 MFMAs per block instead of 72 --, one in every second step for T = 7: 176 instead of 168).
+// A body is a list of PHASES, each with its own register set, in a fixed rotation of four sets: the set a phase has just
+// consumed is reloaded, at the start of the next phase, for the phase three further on -- every load has three phases (48 - 96
+// MFMAs of this wave) to land -- and every wait count follows from the table (v2q_wait).  kind 0 = hi * hi of `b` taps from tap `a`
+// of block `blk`; kind 1 = cross term `b` of macro step `a`, run in the block whose slab completes its K groups (step q covers pairs
+// 4 q .. 4 q + 3 = blocks (4 q) / T .. (4 q + 3) / T, at most two; both slabs are resident: ring of three buffers).  Some two-tap
+// phases are split into single taps so that the phase count is a multiple of the four sets.
+// A phase runs during block `blk` of the quad (the slabs of blocks blk - 1 and blk are resident then).  kind 1: a = macro step,
+// b = term.  kind 0: tap b of block a and, unless c < 0, tap d of block c (a, c in {blk - 1, blk}).
+struct V2Phase { int kind, blk, a, b, c, d; };
+template <int T> struct V2Q;
+template <> struct V2Q<3> {
+  static constexpr int NPH = 16, NX = 3, NS = 4;
+  static constexpr V2Phase ph[NPH] = {{0, 0, 0, 0, 0, 1}, {0, 0, 0, 2, -1, 0},
+                                      {1, 1, 0, 0, 0, 0}, {1, 1, 0, 1, 0, 0}, {0, 1, 1, 0, 1, 1}, {0, 1, 1, 2, -1, 0},
+                                      {1, 2, 1, 0, 0, 0}, {1, 2, 1, 1, 0, 0}, {0, 2, 2, 0, -1, 0}, {0, 2, 2, 1, -1, 0}, {0, 2, 2, 2, -1, 0},
+                                      {1, 3, 2, 0, 0, 0}, {1, 3, 2, 1, 0, 0}, {0, 3, 3, 0, -1, 0}, {0, 3, 3, 1, -1, 0}, {0, 3, 3, 2, -1, 0}};
+};
+// 7 taps: thirty phases on a rotation of THREE sets (a load has two phases = 32 - 64 MFMAs to land, the shortest lead of the
+// hand-written bodies; a fourth set does not fit beside the 64 accumulators and two fragment slots of this body's phases).
+//   steps: q0 = block 0 taps 0-3 | q1 = b0 t4-6, b1 t0 | q2 = b1 t1-4 | q3 = b1 t5-6, b2 t0-1 | q4 = b2 t2-5 | q5 = b2 t6, b3 t0-2 | q6 = b3 t3-6
+template <> struct V2Q<7> {
+  static constexpr int NPH = 30, NX = 7, NS = 3;
+  static constexpr V2Phase ph[NPH] = {
+      {1, 0, 0, 0, 0, 0}, {1, 0, 0, 1, 0, 0}, {0, 0, 0, 0, 0, 1}, {0, 0, 0, 2, 0, 3}, {0, 0, 0, 4, 0, 5}, {0, 0, 0, 6, -1, 0},
+      {1, 1, 1, 0, 0, 0}, {1, 1, 1, 1, 0, 0}, {0, 1, 1, 0, 1, 1}, {0, 1, 1, 2, 1, 3}, {1, 1, 2, 0, 0, 0}, {1, 1, 2, 1, 0, 0}, {0, 1, 1, 4, 1, 5}, {0, 1, 1, 6, -1, 0},
+      {1, 2, 3, 0, 0, 0}, {1, 2, 3, 1, 0, 0}, {0, 2, 2, 0, 2, 1}, {0, 2, 2, 2, 2, 3}, {1, 2, 4, 0, 0, 0}, {1, 2, 4, 1, 0, 0}, {0, 2, 2, 4, 2, 5}, {0, 2, 2, 6, -1, 0},
+      {1, 3, 5, 0, 0, 0}, {1, 3, 5, 1, 0, 0}, {0, 3, 3, 0, 3, 1}, {0, 3, 3, 2, 3, 3}, {1, 3, 6, 0, 0, 0}, {1, 3, 6, 1, 0, 0}, {0, 3, 3, 4, 3, 5}, {0, 3, 3, 6, -1, 0}};
+};
+template <class Q> constexpr int v2q_mod(int i) { return ((i % Q::NPH) + Q::NPH) % Q::NPH; }
+template <class Q> constexpr int v2q_loads(int i) { return Q::ph[v2q_mod<Q>(i)].kind == 1 || Q::ph[v2q_mod<Q>(i)].c >= 0 ? 4 : 2; }
+template <class Q> constexpr bool v2q_first(int i) { return v2q_mod<Q>(i) == 0 || Q::ph[v2q_mod<Q>(i)].blk != Q::ph[v2q_mod<Q>(i) - 1].blk; }
+template <class Q> constexpr bool v2q_end(int i) { return v2q_mod<Q>(i) == Q::NPH - 1 || Q::ph[v2q_mod<Q>(i)].blk != Q::ph[v2q_mod<Q>(i) + 1].blk; }
 // does phase j (relative to this quad; negative = the quad before, which is never the last) issue a set / a slab?
-constexpr bool v2q_has_set(int j, bool last) { return j + 3 < 16 || !last; }
-constexpr bool v2q_has_slab(int j, bool last) { return v2q_first(j + 16) && (j < 0 || !(last && kQuad[j].blk == 3)); }
-// operations in flight behind the set of phase i when it is awaited: the issues of phases i - 3 (its slab only), i - 2, i - 1,
-// each "set for the phase three on, then the slab of the next block if the phase opens a block"
-constexpr int v2q_wait(int i, bool last) {
+template <class Q> constexpr bool v2q_has_set(int j, bool last) { return j + Q::NS - 1 < Q::NPH || !last; }
+template <class Q> constexpr bool v2q_has_slab(int j, bool last) { return v2q_first<Q>(j) && (j < 0 || !(last && Q::ph[j].blk == 3)); }
+// operations in flight behind the set of phase i when it is awaited: the issues of phases i - (NS - 1) (its slab only) .. i - 1,
+// each "set for the phase NS - 1 on, then the slab of the next block if the phase opens a block"
+template <class Q> constexpr int v2q_wait(int i, bool last) {
   int n = 0;
-  for (int j = i - 3; j <= i - 1; ++j) {
-    if (j != i - 3 && v2q_has_set(j, last)) n += v2q_loads(j + 3 + 16);
-    if (v2q_has_slab(j, last)) n += 5;
+  for (int j = i - (Q::NS - 1); j <= i - 1; ++j) {
+    if (j != i - (Q::NS - 1) && v2q_has_set<Q>(j, last)) n += v2q_loads<Q>(j + Q::NS - 1);
+    if (v2q_has_slab<Q>(j, last)) n += 5;
   }
   return n;
 }
 // before the barrier that ends a block: everything issued behind its slab = the sets issued by its later phases
-constexpr int v2q_wait_slab(int iend, bool last) {
+template <class Q> constexpr int v2q_wait_slab(int iend, bool last) {
   int n = 0;
-  for (int j = iend; j >= 0 && !v2q_first(j); --j)
-    if (v2q_has_set(j, last)) n += v2q_loads(j + 3);
+  for (int j = iend; j >= 0 && !v2q_first<Q>(j); --j)
+    if (v2q_has_set<Q>(j, last)) n += v2q_loads<Q>(j + Q::NS - 1);
   return n;
 }
+template <class F, int... I>
+__device__ __forceinline__ void v2q_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>()), ...); }
 
 }  // namespace
 
@@ -101,7 +122,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   constexpr int NQ = (NTAPS + 3) / 4;    // macro steps (groups of four taps) per channel block
   constexpr int NGRP = v2_groups(NTAPS), V2_DA_BYTES = v2_slab_bytes(NTAPS);
   constexpr int NSLOT = 2;               // fragment slots per phase: tile g + 1 is read while tile g multiplies
-  constexpr int RING = (NTAPS == 5 || NTAPS == 3) ? 3 : 2;   // slab buffers (3, 5 taps: a macro step spans two channel blocks, both stay resident)
+  constexpr int RING = NTAPS == 9 ? 2 : 3;   // slab buffers (3, 5, 7 taps: a macro step spans two channel blocks, both stay resident)
   const int tid = threadIdx.x;
   int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,8 +173,10 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   const char* Wm = reinterpret_cast<const char*>(p.Wfr) + (int64_t)nb * ncb * (8 * NQ) * kMainCt;     // [cb][4 NQ taps][2 tiles][1 KB]
   // cross weights: [cb][q][term][2 tiles][2 KB]; 5 taps: [pair of channel blocks][3 macro steps][term][2 tiles][2 KB]
   //                3 taps: [quad of channel blocks][3 macro steps][term][2 tiles][2 KB]
+  //                7 taps: [quad][7 macro steps][term][2 tiles][2 KB]
   const char* Wx = reinterpret_cast<const char*>(p.Wx6) + (NTAPS == 5 ? (int64_t)nb * (ncb >> 1) * 12 * kXCt
-                                                            : NTAPS == 3 ? (int64_t)nb * (ncb >> 2) * 12 * kXCt : (int64_t)nb * ncb * (4 * NQ) * kXCt);
+                                                            : (NTAPS == 3 || NTAPS == 7) ? (int64_t)nb * (ncb >> 2) * (4 * NTAPS) * kXCt
+                                                                                         : (int64_t)nb * ncb * (4 * NQ) * kXCt);
   auto load_w2 = [&](WSet& W, int cb, int tap0) __attribute__((always_inline)) {
     const int voA = lane_now() << 4;
     const char* b = Wm + ((int64_t)cb * (8 * NQ) + tap0 * 2) * kMainCt;
@@ -256,22 +279,26 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     }
   };
 
-  if constexpr (NTAPS == 3) {
-    // ---- the ResNet form (3 x 3 on the zero-bordered grid = three taps along time over the 3 C channels of a kernel row): quads of
-    //      channel blocks on the sixteen-phase rotation described at kQuad
+  if constexpr (NTAPS == 3 || NTAPS == 7) {
+    // ---- quads of channel blocks on the generated schedule V2Q<NTAPS> (3 taps = the ResNet form: 3 x 3 on the zero-bordered grid
+    //      as three taps along time over the 3 C channels of a kernel row)
+    using Q = V2Q<NTAPS>;
     struct RSet { v4i r[4]; };             // a cross set {codes 0-15, tail | scale} x 2 channel tiles, or main weights [tap][tile]
-    RSet S[4];
+    RSet S[Q::NS];
     auto load_set = [&](RSet& R, int cbq, auto idx) __attribute__((always_inline)) {   // the set of phase idx of the quad at cbq
-      constexpr V2Phase ph = kQuad[decltype(idx)::value & 15];
+      constexpr V2Phase ph = Q::ph[v2q_mod<Q>(decltype(idx)::value)];
       const int voA = lane_now() << 4;
       if constexpr (ph.kind == 1) {
-        const char* b = Wx + ((((int64_t)(cbq >> 2) * 3 + ph.a) * 2 + ph.b) * 2) * kXCt;
+        const char* b = Wx + ((((int64_t)(cbq >> 2) * Q::NX + ph.a) * 2 + ph.b) * 2) * kXCt;
         V2_GLD16(R.r[0], voA, b, 0); V2_GLD16(R.r[1], voA, b, 1024);
         V2_GLD16(R.r[2], voA, b, 2048); V2_GLD16(R.r[3], voA, b, 3072);
       } else {
-        const char* b = Wm + ((int64_t)(cbq + ph.blk) * (8 * NQ) + ph.a * 2) * kMainCt;
+        const char* b = Wm + ((int64_t)(cbq + ph.a) * (8 * NQ) + ph.b * 2) * kMainCt;
         V2_GLD16(R.r[0], voA, b, 0); V2_GLD16(R.r[1], voA, b, 1024);
-        if constexpr (ph.b == 2) { V2_GLD16(R.r[2], voA, b, 2048); V2_GLD16(R.r[3], voA, b, 3072); }
+        if constexpr (ph.c >= 0) {
+          const char* b2 = Wm + ((int64_t)(cbq + ph.c) * (8 * NQ) + ph.d * 2) * kMainCt;
+          V2_GLD16(R.r[2], voA, b2, 0); V2_GLD16(R.r[3], voA, b2, 1024);
+        }
       }
     };
     auto x_phase_s = [&](const RSet& X, int ob, int term) __attribute__((always_inline)) {
@@ -297,12 +324,12 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    auto m_phase_s = [&](const RSet& W, int cb, int tap0, int nt) __attribute__((always_inline)) {
-      const char* slab = smem + buf_of(cb) * V2_DA_BYTES;
+    auto m_phase_s = [&](const RSet& W, int cbA, int tapA, int cbB, int tapB, int nt) __attribute__((always_inline)) {
+      const char* slab = smem;
       int of[2];
       const int l = lane_now();
-#pragma unroll
-      for (int j = 0; j < 2; ++j) of[j] = j < nt ? main_off(l, tap0 + j) : 0;
+      of[0] = buf_of(cbA) * V2_DA_BYTES + main_off(l, tapA);
+      of[1] = nt > 1 ? buf_of(cbB) * V2_DA_BYTES + main_off(l, tapB) : 0;
       f16x8 fm[NSLOT][2];
       auto rd = [&](int g, int s) __attribute__((always_inline)) {
 #pragma unroll
@@ -325,13 +352,13 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    // K groups of macro step q (in block q + 1 of the quad at cbq): pair 4 q + g = block (4 q + g) / 3, tap (4 q + g) % 3 -- two
-    // neighbouring blocks, chosen by a select
+    // K groups of macro step q of the quad at cbq: pair 4 q + g = block (4 q + g) / T, tap (4 q + g) % T -- at most two neighbouring
+    // blocks, chosen by a select
     auto ob_of = [&](int cbq, int q) __attribute__((always_inline)) {
       const int l = lane_now(), pr = 4 * q + (l >> 4);
-      const int lo = (4 * q) / 3;
-      const int hi_sel = pr >= 3 * (lo + 1);
-      const int tap = pr - 3 * (lo + hi_sel);
+      const int lo = (4 * q) / NTAPS;
+      const int hi_sel = pr >= NTAPS * (lo + 1);
+      const int tap = pr - NTAPS * (lo + hi_sel);
       const int b_lo = buf_of(cbq + lo) * V2_DA_BYTES, b_hi = buf_of(cbq + lo + 1) * V2_DA_BYTES;
       return cross_at(l, hi_sel ? b_hi : b_lo, tap);
     };
@@ -339,41 +366,43 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     for (int g = wave; g < NGRP; g += 4) dma_a(cb_begin, buf_of(cb_begin), g, lane_now());
     load_set(S[0], cb_begin, std::integral_constant<int, 0>());
     load_set(S[1], cb_begin, std::integral_constant<int, 1>());
-    load_set(S[2], cb_begin, std::integral_constant<int, 2>());
+    if constexpr (Q::NS == 4) load_set(S[2], cb_begin, std::integral_constant<int, 2>());
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     auto quad = [&](int cbq, auto last_tag) __attribute__((always_inline)) {
       constexpr bool last = decltype(last_tag)::value;
       auto phase = [&](auto idx) __attribute__((always_inline)) {
         constexpr int i = decltype(idx)::value;
-        constexpr V2Phase ph = kQuad[i];
-        RSet& R = S[i & 3];
-        if constexpr (ph.kind == 0 && ph.b == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(R.r[0]), "+v"(R.r[1]) : "n"(v2q_wait(i, last)));
-        else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(R.r[0]), "+v"(R.r[1]), "+v"(R.r[2]), "+v"(R.r[3]) : "n"(v2q_wait(i, last)));
-        if constexpr (v2q_has_set(i, last)) load_set(S[(i + 3) & 3], i + 3 < 16 ? cbq : cbq + 4, std::integral_constant<int, (i + 3) & 15>());
-        if constexpr (v2q_has_slab(i, last)) dma_next(cbq + ph.blk);
+        constexpr V2Phase ph = Q::ph[i];
+        RSet& R = S[i % Q::NS];
+        if constexpr (ph.kind == 0 && ph.c < 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(R.r[0]), "+v"(R.r[1]) : "n"(v2q_wait<Q>(i, last)));
+        else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(R.r[0]), "+v"(R.r[1]), "+v"(R.r[2]), "+v"(R.r[3]) : "n"(v2q_wait<Q>(i, last)));
+        if constexpr (v2q_has_set<Q>(i, last))
+          load_set(S[(i + Q::NS - 1) % Q::NS], i + Q::NS - 1 < Q::NPH ? cbq : cbq + 4, std::integral_constant<int, (i + Q::NS - 1) % Q::NPH>());
+        if constexpr (v2q_has_slab<Q>(i, last)) dma_next(cbq + ph.blk);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ph.kind == 1) x_phase_s(R, ob_of(cbq, ph.a), ph.b);
-        else m_phase_s(R, cbq + ph.blk, ph.a, ph.b);
-        if constexpr (v2q_end(i)) {
+        else m_phase_s(R, cbq + ph.a, ph.b, cbq + (ph.c < 0 ? ph.a : ph.c), ph.d, ph.c < 0 ? 1 : 2);
+        if constexpr (v2q_end<Q>(i)) {
           // the block's slab pieces (issued by its first phase) have landed before the barrier hands the buffer over
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(v2q_wait_slab(i, last)) : "memory");
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(v2q_wait_slab<Q>(i, last)) : "memory");
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();                // every wave is done with the slab two blocks back; the next one is visible
+          if constexpr (NTAPS == 7) {     // (live-range seam for the allocator, as at the hand-over to the last body)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(acc[g][0]), "+v"(acc[g][1]));
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       };
-      phase(std::integral_constant<int, 0>()); phase(std::integral_constant<int, 1>()); phase(std::integral_constant<int, 2>());
-      phase(std::integral_constant<int, 3>()); phase(std::integral_constant<int, 4>()); phase(std::integral_constant<int, 5>());
-      phase(std::integral_constant<int, 6>()); phase(std::integral_constant<int, 7>()); phase(std::integral_constant<int, 8>());
-      phase(std::integral_constant<int, 9>()); phase(std::integral_constant<int, 10>()); phase(std::integral_constant<int, 11>());
-      phase(std::integral_constant<int, 12>()); phase(std::integral_constant<int, 13>()); phase(std::integral_constant<int, 14>());
-      phase(std::integral_constant<int, 15>());
+      v2q_for(phase, std::make_integer_sequence<int, Q::NPH>());
     };
     for (int cb = cb_begin; cb + 4 < cb_end; cb += 4) quad(cb, std::false_type());
 #pragma unroll
     for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(acc[g][0]), "+v"(acc[g][1]));
     quad(cb_end - 4, std::true_type());
+#pragma unroll
+    for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(acc[g][0]), "+v"(acc[g][1]));     // (and again towards the epilogue)
   } else {
   XSet XA, XB;
   WSet WA, WB;
@@ -381,7 +410,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   for (int g = wave; g < NGRP; g += 4) dma_a(cb_begin, buf_of(cb_begin), g, lane_now());
   load_x(XA, NTAPS == 5 ? cb_begin >> 1 : cb_begin, 0, 0);
   load_x(XB, NTAPS == 5 ? cb_begin >> 1 : cb_begin, 0, 1);
-  if (NTAPS == 7 || NTAPS == 5) load_w2(WA, cb_begin, 0);
+  if (NTAPS == 5) load_w2(WA, cb_begin, 0);
   else load_w2(WB, cb_begin, 2);           // (5 and 9 taps issue WA = taps 0, 1 at the top of the channel block)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -396,39 +425,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   auto body = [&](int cb, auto last_tag) __attribute__((always_inline)) {
     constexpr bool last = decltype(last_tag)::value;
     const int nx = cb + 1;
-    if constexpr (NTAPS == 7) {
-      V2_WAITX(8, XA);
-      if constexpr (!last) dma_next(cb);
-      load_w2(WB, cb, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XA, cb, 0, 0);
-      if constexpr (!last) V2_WAITX(13, XB); else V2_WAITX(8, XB);
-      load_x(XA, cb, 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XB, cb, 0, 1);
-      if constexpr (!last) V2_WAITW2(13, WA); else V2_WAITW2(8, WA);
-      load_x(XB, cb, 1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WA, cb, 0, 2);
-      V2_WAITW2(8, WB);
-      load_w2(WA, cb, 4);
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WB, cb, 2, 2);
-      V2_WAITX(8, XA);
-      load_w1(WB, cb, 6);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XA, cb, 1, 0);
-      V2_WAITX(6, XB);
-      if constexpr (!last) load_x(XA, nx, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XB, cb, 1, 1);
-      if constexpr (!last) { V2_WAITW2(6, WA); load_x(XB, nx, 0, 1); } else { V2_WAITW2(2, WA); }
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WA, cb, 4, 2);
-      if constexpr (!last) { V2_WAITW1(8, WB); load_w2(WA, nx, 0); } else { V2_WAITW1(0, WB); }
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WB, cb, 6, 1);
-    } else if constexpr (NTAPS == 9) {
+    if constexpr (NTAPS == 9) {
       //   9 taps  XA0: WA(0,1) x4, slab x5 | XB0: XA(q1) x4 | M01: XB(q1) x4 | M23: WA(4,5) x4 | XA1: WB(6,7) x4 | XB1: XA(q2) x4 | M45: XB(q2) x4 |
       //           M67: WA(8) x2 | XA2: WB(2,3)' x4 | XB2: XA(q0') x4 | M8: XB(q0') x4
       //   waits   XA0 4   XB0 9 (4)   M01 9 (4)   M23 8   XA1 8   XB1 8   M45 8   M67 8   XA2 6   XB2 6 (2)   M8 8 (0)
@@ -726,7 +723,7 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   static std::mutex mu;
   static bool attr_set[64] = {};
-  const size_t smem = (size_t)(taps == 5 || taps == 3 ? 3 : 2) * v2_slab_bytes(taps);
+  const size_t smem = (size_t)(taps == 9 ? 2 : 3) * v2_slab_bytes(taps);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   {
@@ -745,9 +742,9 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
   }
   const int nMt = ((a.M + V2_BM - 1) / V2_BM) * (bins ? a.nbin : 1), nNt = a.Npad / V2_BN, ncb = a.cin >> 5;
   if (taps == 5 && (ncb & 1)) return hipErrorInvalidValue;      // the 5-tap body takes channel blocks in pairs,
-  if (taps == 3 && (ncb & 3)) return hipErrorInvalidValue;      // the 3-tap body in quads
+  if ((taps == 3 || taps == 7) && (ncb & 3)) return hipErrorInvalidValue;      // the 3- and 7-tap bodies in quads
   const bool tail = !bins && a.tail_mt > 0 && (a.ksplit == 2 || a.ksplit == 4 || a.ksplit == 8) && a.partial && a.tail_mt < nMt && ncb % a.ksplit == 0 &&
-                    (taps != 5 || (ncb / a.ksplit) % 2 == 0);
+                    (taps != 5 || (ncb / a.ksplit) % 2 == 0) && (taps != 7 || (ncb / a.ksplit) % 4 == 0);
   const int nMain = tail ? nMt - a.tail_mt : nMt;
   const int S = tail ? a.ksplit : 0;
   const dim3 grid(nMain * nNt + (tail ? a.tail_mt * nNt * a.ksplit : 0)), block(256);

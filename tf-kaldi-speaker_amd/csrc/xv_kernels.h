@@ -123,7 +123,8 @@ int gemm_f32_ksplit(int M, int Kpad, int Npad);
 // Tail balancing of the bf16x3 kernel (1-D layers): when the last round of 128x128 tiles over the chip's 768
 // workgroup slots would be nearly empty, its M tiles are split along K into `*splits` slices each (deterministic:
 // raw partials + an ordered reduce).  Returns the partial workspace in bytes (0 = no tail handling).
-int64_t gemm_bf16x3_tail_plan(int M, int Kpad, int Npad, int w, int* tail_mt, int* splits);
+// (cb_quant: a slice must hold a multiple of this many channel blocks -- the two-unit kernel takes them in pairs (5 taps) or quads (7))
+int64_t gemm_bf16x3_tail_plan(int M, int Kpad, int Npad, int w, int* tail_mt, int* splits, int cb_quant = 1);
 
 // fp32 frames -> split-blocked im2col rows for a small-cin first layer:
 //   out row m, k < w*cin: x[(m + k / cin) * ldx + k % cin]; zero padded to ldsb columns.
