@@ -38,9 +38,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lptr2_t;
 
 constexpr int V2_BM = 128, V2_BN = 128, V2_DROW = 128;
-// slab rows: 128 frames + the halo of the last tap group (a group of four taps reads up to row 15 + 4 q + 3 of the last tile), in
-// whole 8-row DMA pieces: 136 rows for two macro steps (5 / 7 taps), 144 for three (9 taps)
-constexpr int v2_groups(int ntaps) { return ntaps <= 8 ? 17 : 18; }
+// slab rows: 128 frames + the halo of the last tap (a K group of the cross terms reads row frame + its tap, like the main pass), in
+// whole 8-row DMA pieces: 136 rows for up to nine taps
+constexpr int v2_groups(int ntaps) { return ntaps <= 9 ? 17 : 18; }
 constexpr int v2_slab_bytes(int ntaps) { return v2_groups(ntaps) * 8 * V2_DROW; }
 constexpr int64_t kMainCt = 64 * 16;               // bytes per (tap, 16-channel tile) of the main weights: 64 lanes x 16 B
 constexpr int64_t kXCt = 2 * 64 * 16;              // per (macro step, term, 16-channel tile) of the cross weights: 64 x 16 B codes 0-15 |
@@ -80,6 +80,18 @@ template <> struct V2Q<7> {
       {1, 1, 1, 0, 0, 0}, {1, 1, 1, 1, 0, 0}, {0, 1, 1, 0, 1, 1}, {0, 1, 1, 2, 1, 3}, {1, 1, 2, 0, 0, 0}, {1, 1, 2, 1, 0, 0}, {0, 1, 1, 4, 1, 5}, {0, 1, 1, 6, -1, 0},
       {1, 2, 3, 0, 0, 0}, {1, 2, 3, 1, 0, 0}, {0, 2, 2, 0, 2, 1}, {0, 2, 2, 2, 2, 3}, {1, 2, 4, 0, 0, 0}, {1, 2, 4, 1, 0, 0}, {0, 2, 2, 4, 2, 5}, {0, 2, 2, 6, -1, 0},
       {1, 3, 5, 0, 0, 0}, {1, 3, 5, 1, 0, 0}, {0, 3, 3, 0, 3, 1}, {0, 3, 3, 2, 3, 3}, {1, 3, 6, 0, 0, 0}, {1, 3, 6, 1, 0, 0}, {0, 3, 3, 4, 3, 5}, {0, 3, 3, 6, -1, 0}};
+};
+// 9 taps: 36 pairs = nine macro steps (one block at a time: twelve slots per block, three of them zero: 240 MFMAs per block
+// instead of 216).  q0 = b0 t0-3 | q1 = b0 t4-7 | q2 = b0 t8, b1 t0-2 | q3 = b1 t3-6 | q4 = b1 t7-8, b2 t0-1 | q5 = b2 t2-5 |
+// q6 = b2 t6-8, b3 t0 | q7 = b3 t1-4 | q8 = b3 t5-8.  39 phases on three sets.
+template <> struct V2Q<9> {
+  static constexpr int NPH = 39, NX = 9, NS = 3;
+  static constexpr V2Phase ph[NPH] = {
+      {1, 0, 0, 0, 0, 0}, {1, 0, 0, 1, 0, 0}, {0, 0, 0, 0, 0, 1}, {0, 0, 0, 2, 0, 3}, {1, 0, 1, 0, 0, 0}, {1, 0, 1, 1, 0, 0}, {0, 0, 0, 4, 0, 5}, {0, 0, 0, 6, 0, 7}, {0, 0, 0, 8, -1, 0},
+      {1, 1, 2, 0, 0, 0}, {1, 1, 2, 1, 0, 0}, {0, 1, 1, 0, 1, 1}, {0, 1, 1, 2, 1, 3}, {1, 1, 3, 0, 0, 0}, {1, 1, 3, 1, 0, 0}, {0, 1, 1, 4, 1, 5}, {0, 1, 1, 6, 1, 7}, {0, 1, 1, 8, -1, 0},
+      {1, 2, 4, 0, 0, 0}, {1, 2, 4, 1, 0, 0}, {0, 2, 2, 0, 2, 1}, {0, 2, 2, 2, 2, 3}, {1, 2, 5, 0, 0, 0}, {1, 2, 5, 1, 0, 0}, {0, 2, 2, 4, 2, 5}, {0, 2, 2, 6, 2, 7}, {0, 2, 2, 8, -1, 0},
+      {1, 3, 6, 0, 0, 0}, {1, 3, 6, 1, 0, 0}, {0, 3, 3, 0, -1, 0}, {0, 3, 3, 1, -1, 0}, {0, 3, 3, 2, 3, 3}, {1, 3, 7, 0, 0, 0}, {1, 3, 7, 1, 0, 0}, {0, 3, 3, 4, 3, 5},
+      {1, 3, 8, 0, 0, 0}, {1, 3, 8, 1, 0, 0}, {0, 3, 3, 6, 3, 7}, {0, 3, 3, 8, -1, 0}};
 };
 template <class Q> constexpr int v2q_mod(int i) { return ((i % Q::NPH) + Q::NPH) % Q::NPH; }
 template <class Q> constexpr int v2q_loads(int i) { return Q::ph[v2q_mod<Q>(i)].kind == 1 || Q::ph[v2q_mod<Q>(i)].c >= 0 ? 4 : 2; }
@@ -122,7 +134,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   constexpr int NQ = (NTAPS + 3) / 4;    // macro steps (groups of four taps) per channel block
   constexpr int NGRP = v2_groups(NTAPS), V2_DA_BYTES = v2_slab_bytes(NTAPS);
   constexpr int NSLOT = 2;               // fragment slots per phase: tile g + 1 is read while tile g multiplies
-  constexpr int RING = NTAPS == 9 ? 2 : 3;   // slab buffers (3, 5, 7 taps: a macro step spans two channel blocks, both stay resident)
+  constexpr int RING = 3;                // slab buffers: a macro step spans two channel blocks, both stay resident
   const int tid = threadIdx.x;
   int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,9 +186,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   // cross weights: [cb][q][term][2 tiles][2 KB]; 5 taps: [pair of channel blocks][3 macro steps][term][2 tiles][2 KB]
   //                3 taps: [quad of channel blocks][3 macro steps][term][2 tiles][2 KB]
   //                7 taps: [quad][7 macro steps][term][2 tiles][2 KB]
-  const char* Wx = reinterpret_cast<const char*>(p.Wx6) + (NTAPS == 5 ? (int64_t)nb * (ncb >> 1) * 12 * kXCt
-                                                            : (NTAPS == 3 || NTAPS == 7) ? (int64_t)nb * (ncb >> 2) * (4 * NTAPS) * kXCt
-                                                                                         : (int64_t)nb * ncb * (4 * NQ) * kXCt);
+  const char* Wx = reinterpret_cast<const char*>(p.Wx6) + (NTAPS == 5 ? (int64_t)nb * (ncb >> 1) * 12 * kXCt : (int64_t)nb * (ncb >> 2) * (4 * NTAPS) * kXCt);
   auto load_w2 = [&](WSet& W, int cb, int tap0) __attribute__((always_inline)) {
     const int voA = lane_now() << 4;
     const char* b = Wm + ((int64_t)cb * (8 * NQ) + tap0 * 2) * kMainCt;
@@ -279,7 +289,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     }
   };
 
-  if constexpr (NTAPS == 3 || NTAPS == 7) {
+  if constexpr (NTAPS != 5) {
     // ---- quads of channel blocks on the generated schedule V2Q<NTAPS> (3 taps = the ResNet form: 3 x 3 on the zero-bordered grid
     //      as three taps along time over the 3 C channels of a kernel row)
     using Q = V2Q<NTAPS>;
@@ -388,7 +398,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(v2q_wait_slab<Q>(i, last)) : "memory");
           __builtin_amdgcn_sched_barrier(0);
           __syncthreads();                // every wave is done with the slab two blocks back; the next one is visible
-          if constexpr (NTAPS == 7) {     // (live-range seam for the allocator, as at the hand-over to the last body)
+          if constexpr (NTAPS >= 7) {     // (live-range seam for the allocator, as at the hand-over to the last body)
 #pragma unroll
             for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(acc[g][0]), "+v"(acc[g][1]));
           }
@@ -410,8 +420,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   for (int g = wave; g < NGRP; g += 4) dma_a(cb_begin, buf_of(cb_begin), g, lane_now());
   load_x(XA, NTAPS == 5 ? cb_begin >> 1 : cb_begin, 0, 0);
   load_x(XB, NTAPS == 5 ? cb_begin >> 1 : cb_begin, 0, 1);
-  if (NTAPS == 5) load_w2(WA, cb_begin, 0);
-  else load_w2(WB, cb_begin, 2);           // (5 and 9 taps issue WA = taps 0, 1 at the top of the channel block)
+  load_w2(WA, cb_begin, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -425,54 +434,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   auto body = [&](int cb, auto last_tag) __attribute__((always_inline)) {
     constexpr bool last = decltype(last_tag)::value;
     const int nx = cb + 1;
-    if constexpr (NTAPS == 9) {
-      //   9 taps  XA0: WA(0,1) x4, slab x5 | XB0: XA(q1) x4 | M01: XB(q1) x4 | M23: WA(4,5) x4 | XA1: WB(6,7) x4 | XB1: XA(q2) x4 | M45: XB(q2) x4 |
-      //           M67: WA(8) x2 | XA2: WB(2,3)' x4 | XB2: XA(q0') x4 | M8: XB(q0') x4
-      //   waits   XA0 4   XB0 9 (4)   M01 9 (4)   M23 8   XA1 8   XB1 8   M45 8   M67 8   XA2 6   XB2 6 (2)   M8 8 (0)
-      V2_WAITX(4, XA);
-      load_w2(WA, cb, 0);
-      if constexpr (!last) dma_next(cb);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XA, cb, 0, 0);
-      if constexpr (!last) V2_WAITX(9, XB); else V2_WAITX(4, XB);
-      load_x(XA, cb, 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XB, cb, 0, 1);
-      if constexpr (!last) V2_WAITW2(9, WA); else V2_WAITW2(4, WA);
-      load_x(XB, cb, 1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WA, cb, 0, 2);
-      V2_WAITW2(8, WB);
-      load_w2(WA, cb, 4);
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WB, cb, 2, 2);
-      V2_WAITX(8, XA);
-      load_w2(WB, cb, 6);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XA, cb, 1, 0);
-      V2_WAITX(8, XB);
-      load_x(XA, cb, 2, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XB, cb, 1, 1);
-      V2_WAITW2(8, WA);
-      load_x(XB, cb, 2, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WA, cb, 4, 2);
-      V2_WAITW2(8, WB);
-      load_w1(WA, cb, 8);
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WB, cb, 6, 2);
-      V2_WAITX(6, XA);
-      if constexpr (!last) load_w2(WB, nx, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XA, cb, 2, 0);
-      if constexpr (!last) { V2_WAITX(6, XB); load_x(XA, nx, 0, 0); } else { V2_WAITX(2, XB); }
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase(XB, cb, 2, 1);
-      if constexpr (!last) { V2_WAITW1(8, WA); load_x(XB, nx, 0, 1); } else { V2_WAITW1(0, WA); }
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WA, cb, 8, 1);
-    } else {
+    {
       // 5 taps, a PAIR of channel blocks cb, c1 = cb + 1 per body: the ten taps fill three macro steps (12 K groups) instead of
       // four (16) -- q0 = taps 0-3 of cb; q1 = tap 4 of cb + taps 0-2 of c1; q2 = taps 3, 4 of c1 + two groups of zero weights (they
       // read the rows of tap 4 again) -- 128 instead of 144 MFMAs per channel block.  q1 reads both slabs: three slab buffers in a
@@ -723,7 +685,7 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   static std::mutex mu;
   static bool attr_set[64] = {};
-  const size_t smem = (size_t)(taps == 9 ? 2 : 3) * v2_slab_bytes(taps);
+  const size_t smem = (size_t)3 * v2_slab_bytes(taps);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   {
@@ -742,9 +704,9 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
   }
   const int nMt = ((a.M + V2_BM - 1) / V2_BM) * (bins ? a.nbin : 1), nNt = a.Npad / V2_BN, ncb = a.cin >> 5;
   if (taps == 5 && (ncb & 1)) return hipErrorInvalidValue;      // the 5-tap body takes channel blocks in pairs,
-  if ((taps == 3 || taps == 7) && (ncb & 3)) return hipErrorInvalidValue;      // the 3- and 7-tap bodies in quads
+  if (taps != 5 && (ncb & 3)) return hipErrorInvalidValue;      // the other bodies in quads
   const bool tail = !bins && a.tail_mt > 0 && (a.ksplit == 2 || a.ksplit == 4 || a.ksplit == 8) && a.partial && a.tail_mt < nMt && ncb % a.ksplit == 0 &&
-                    (taps != 5 || (ncb / a.ksplit) % 2 == 0) && (taps != 7 || (ncb / a.ksplit) % 4 == 0);
+                    (ncb / a.ksplit) % (taps == 5 ? 2 : 4) == 0;
   const int nMain = tail ? nMt - a.tail_mt : nMt;
   const int S = tail ? a.ksplit : 0;
   const dim3 grid(nMain * nNt + (tail ? a.tail_mt * nNt * a.ksplit : 0)), block(256);

@@ -817,7 +817,7 @@ int upload_layer(xv_handle* h, Layer& L) {
       // is tap p % 5 of channel block 2 k + p / 5 for p < 10, zero weights for p = 10, 11:  [Npad/32][cin/64][3][2 terms][2 tiles]
       // 3 taps (ResNet form): over QUADS of channel blocks -- slot p = 3 (cb & 3) + tap, twelve slots = three macro steps exactly
       // 7 taps: quads as well, 28 slots = seven macro steps
-      const bool pairs = L.mode == 0 && fw == 5, quads = L.mode == 1 || (L.mode == 0 && fw == 7);
+      const bool pairs = L.mode == 0 && fw == 5, quads = !pairs;
       const size_t xsteps = pairs ? (size_t)(ncb / 2) * 3 : quads ? (size_t)(ncb / 4) * fw : (size_t)ncb * NQ;
       std::vector<unsigned char> wm((size_t)(L.Npad / 32) * ncb * (4 * NQ) * 2 * main_ct, 0), wx((size_t)(L.Npad / 32) * xsteps * 2 * 2 * cross_ct, 0);
       for (int n = 0; n < L.Npad; ++n) {
@@ -974,7 +974,7 @@ int xv_finalize(xv_handle* h) {
       // two-unit split: the 5-, 7- and 9-tap layers over whole 32-channel blocks (the first layer, K = 5 x 30, stays on the f16 kernel and writes
       // the block format of its reader: gemm_bf16x3_w14p2_kernel<1, 3, true>)
       L.use_f6 = h->desc.precision == XV_PREC_F16F6 && L.use_split && !L.im2col && (L.w == 5 || L.w == 7 || L.w == 9) &&
-                 L.cin % (L.w == 5 ? 64 : L.w == 7 ? 128 : 32) == 0 && L.cout % 4 == 0;      // (5 taps: channel blocks in pairs, 7: in quads)
+                 L.cin % (L.w == 5 ? 64 : 128) == 0 && L.cout % 4 == 0;      // (5 taps: channel blocks in pairs, 7 / 9: in quads)
     } else {      // grid convolutions: whole SB blocks per tap; conv0 goes through its own im2col
       L.use_split = bf && (L.mode == 4 || L.cin % 32 == 0);
       // two-unit split of the stride-1 3 x 3 convolutions: three taps along time over the 3 C channels of a kernel row
@@ -1340,7 +1340,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       } else if (L.use_f6) {
         scratch = (st.rows_in + kSlackRows) * (int64_t)sb_ld(L.cin) * 4;      // the input in the block format of gemm_f16f6.hip
         if (h->opt_tail_split && op.in1 <= 0 && L.mode == 0) {
-          const int64_t part = gemm_bf16x3_tail_plan(st.M, L.Kpad, L.Npad, L.w, &st.tail_mt, &st.ksplit, L.w == 5 ? 2 : (L.w == 7 ? 4 : 1));
+          const int64_t part = gemm_bf16x3_tail_plan(st.M, L.Kpad, L.Npad, L.w, &st.tail_mt, &st.ksplit, L.w == 5 ? 2 : 4);
           if (part > 0) {
             step_scratch2 = align_up(part, kAlign);
             st.scratch2_off = arena_alloc(step_scratch2);
