@@ -245,8 +245,8 @@ def test_f16f6_two_unit_split(net):
     from oracle import ref_numpy
     from tf_kaldi_speaker_amd import synth
     import torch
-    ch = {"tdnn_narrow": 64, "tdnn_128": 128}.get(net, 512)     # 64: one pair of channel blocks for the 5-tap layer, the 7-tap layer (whole
-                                                                  # quads only) stays on f16x3; 128: exactly one pair / one quad = the peeled last body alone
+    ch = {"tdnn_narrow": 64, "tdnn_128": 128}.get(net, 512)     # 64: two channel blocks, no quad: every layer stays on the f16x3 kernels (the
+                                                                  # fallback); 128: exactly one quad = the peeled last body alone
     params = dict(synth.TDNN_STAT_PARAMS)
     if net == "etdnn":                                  # conv1d k = 5, 5, 7, 9 at tdnn1 / 3 / 5 / 7 (model/tdnn.py:343-591)
         params.update(network_type="extended_tdnn", embedding_node="tdnn12_dense")
@@ -271,7 +271,8 @@ def test_f16f6_two_unit_split(net):
     tr.close()
     for node in nodes[:-1]:
         assert _rel2(got[node], exact[node]) <= 5e-5, (net, node, _rel2(got[node], exact[node]))
-        assert _rel2(got[node], exact[node]) >= 1e-6, (net, node, "the two-unit kernel did not run")
+        if net != "tdnn_narrow":
+            assert _rel2(got[node], exact[node]) >= 1e-6, (net, node, "the two-unit kernel did not run")
     for i in (0, 3, 5):
         ref = ref_numpy.predict(utts[i], weights, params, 30)
         assert _rel(got[emb][i], ref) <= TOL, (net, i)

@@ -46,10 +46,6 @@ constexpr int64_t kMainCt = 64 * 16;               // bytes per (tap, 16-channel
 constexpr int64_t kXCt = 2 * 64 * 16;              // per (macro step, term, 16-channel tile) of the cross weights: 64 x 16 B codes 0-15 |
                                                    // 64 x 16 B {codes 16-23, scale dword, pad}: one lane offset serves both planes
 
-struct XSet { v4i c[2]; v4i t[2]; };               // per channel tile: bytes 0-15 of the 6-bit codes; {bytes 16-23, E8M0 scale (byte 0), pad}:
-                                                   // two halves of one 8-register operand tuple (the scaled MFMA reads the first six)
-struct WSet { f16x8 w[2][2]; };                    // [tap of the pair][channel tile]
-
 // Generated schedules.  The 3-tap (ResNet) and the 7-tap form run a QUAD of channel blocks per loop body: 4 T (block, tap) pairs
 // fill T macro steps of the cross terms exactly (one block at a time needs ceil(T / 4) steps of four K groups per block: a zero K
 // group in every block for T = 3 -- 80 MFMAs per block instead of 72 --, one in every second step for T = 7: 176 instead of 168).
@@ -80,6 +76,16 @@ template <> struct V2Q<7> {
       {1, 1, 1, 0, 0, 0}, {1, 1, 1, 1, 0, 0}, {0, 1, 1, 0, 1, 1}, {0, 1, 1, 2, 1, 3}, {1, 1, 2, 0, 0, 0}, {1, 1, 2, 1, 0, 0}, {0, 1, 1, 4, 1, 5}, {0, 1, 1, 6, -1, 0},
       {1, 2, 3, 0, 0, 0}, {1, 2, 3, 1, 0, 0}, {0, 2, 2, 0, 2, 1}, {0, 2, 2, 2, 2, 3}, {1, 2, 4, 0, 0, 0}, {1, 2, 4, 1, 0, 0}, {0, 2, 2, 4, 2, 5}, {0, 2, 2, 6, -1, 0},
       {1, 3, 5, 0, 0, 0}, {1, 3, 5, 1, 0, 0}, {0, 3, 3, 0, 3, 1}, {0, 3, 3, 2, 3, 3}, {1, 3, 6, 0, 0, 0}, {1, 3, 6, 1, 0, 0}, {0, 3, 3, 4, 3, 5}, {0, 3, 3, 6, -1, 0}};
+};
+// 5 taps: 20 pairs = five macro steps (one block at a time: eight slots per block, three of them zero: 144 MFMAs per block instead
+// of 120).  q0 = b0 t0-3 | q1 = b0 t4, b1 t0-2 | q2 = b1 t3-4, b2 t0-1 | q3 = b2 t2-4, b3 t0 | q4 = b3 t1-4.  24 phases on three sets.
+template <> struct V2Q<5> {
+  static constexpr int NPH = 24, NX = 5, NS = 3;
+  static constexpr V2Phase ph[NPH] = {
+      {1, 0, 0, 0, 0, 0}, {1, 0, 0, 1, 0, 0}, {0, 0, 0, 0, -1, 0}, {0, 0, 0, 1, -1, 0}, {0, 0, 0, 2, 0, 3}, {0, 0, 0, 4, -1, 0},
+      {1, 1, 1, 0, 0, 0}, {1, 1, 1, 1, 0, 0}, {0, 1, 1, 0, -1, 0}, {0, 1, 1, 1, -1, 0}, {0, 1, 1, 2, 1, 3}, {0, 1, 1, 4, -1, 0},
+      {1, 2, 2, 0, 0, 0}, {1, 2, 2, 1, 0, 0}, {0, 2, 2, 0, 2, 1}, {0, 2, 2, 2, 2, 3}, {0, 2, 2, 4, -1, 0},
+      {1, 3, 3, 0, 0, 0}, {1, 3, 3, 1, 0, 0}, {0, 3, 3, 0, 3, 1}, {0, 3, 3, 2, 3, 3}, {1, 3, 4, 0, 0, 0}, {1, 3, 4, 1, 0, 0}, {0, 3, 3, 4, -1, 0}};
 };
 // 9 taps: 36 pairs = nine macro steps (one block at a time: twelve slots per block, three of them zero: 240 MFMAs per block
 // instead of 216).  q0 = b0 t0-3 | q1 = b0 t4-7 | q2 = b0 t8, b1 t0-2 | q3 = b1 t3-6 | q4 = b1 t7-8, b2 t0-1 | q5 = b2 t2-5 |
@@ -123,11 +129,6 @@ __device__ __forceinline__ void v2q_for(F&& f, std::integer_sequence<int, I...>)
 }  // namespace
 
 #define V2_GLD16(dst, voff, sbase, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(dst) : "v"(voff), "s"(sbase))
-// the waits name the registers they release, so that no MFMA of the phase can be scheduled above them
-#define V2_WAITX(N, X) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(X.c[0]), "+v"(X.c[1]), "+v"(X.t[0]), "+v"(X.t[1]))
-#define V2_WAITW2(N, W) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(W.w[0][0]), "+v"(W.w[0][1]), "+v"(W.w[1][0]), "+v"(W.w[1][1]))
-#define V2_WAITW1(N, W) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(W.w[0][0]), "+v"(W.w[0][1]))
-
 template <int NTAPS, bool OUT_F6, bool RES>
 __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, char* smem, int cb_begin, int cb_end, bool slice, int bin = 0) {
   static_assert(NTAPS == 3 || NTAPS == 5 || NTAPS == 7 || NTAPS == 9, "taps");
@@ -186,24 +187,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
   // cross weights: [cb][q][term][2 tiles][2 KB]; 5 taps: [pair of channel blocks][3 macro steps][term][2 tiles][2 KB]
   //                3 taps: [quad of channel blocks][3 macro steps][term][2 tiles][2 KB]
   //                7 taps: [quad][7 macro steps][term][2 tiles][2 KB]
-  const char* Wx = reinterpret_cast<const char*>(p.Wx6) + (NTAPS == 5 ? (int64_t)nb * (ncb >> 1) * 12 * kXCt : (int64_t)nb * (ncb >> 2) * (4 * NTAPS) * kXCt);
-  auto load_w2 = [&](WSet& W, int cb, int tap0) __attribute__((always_inline)) {
-    const int voA = lane_now() << 4;
-    const char* b = Wm + ((int64_t)cb * (8 * NQ) + tap0 * 2) * kMainCt;
-    V2_GLD16(W.w[0][0], voA, b, 0); V2_GLD16(W.w[0][1], voA, b, 1024);
-    V2_GLD16(W.w[1][0], voA, b, 2048); V2_GLD16(W.w[1][1], voA, b, 3072);
-  };
-  auto load_w1 = [&](WSet& W, int cb, int tap0) __attribute__((always_inline)) {
-    const int voA = lane_now() << 4;
-    const char* b = Wm + ((int64_t)cb * (8 * NQ) + tap0 * 2) * kMainCt;
-    V2_GLD16(W.w[0][0], voA, b, 0); V2_GLD16(W.w[0][1], voA, b, 1024);
-  };
-  auto load_x = [&](XSet& X, int cb, int q, int term) __attribute__((always_inline)) {       // (5 taps: cb = the pair's index, q < 3)
-    const int voA = lane_now() << 4;
-    const char* b = Wx + ((((int64_t)cb * (NTAPS == 5 ? 3 : NQ) + q) * 2 + term) * 2) * kXCt;
-    V2_GLD16(X.c[0], voA, b, 0); V2_GLD16(X.t[0], voA, b, 1024);
-    V2_GLD16(X.c[1], voA, b, 2048); V2_GLD16(X.t[1], voA, b, 3072);
-  };
+  const char* Wx = reinterpret_cast<const char*>(p.Wx6) + (int64_t)nb * (ncb >> 2) * (4 * NTAPS) * kXCt;
 
   f32x4 acc[8][2];
 #pragma unroll
@@ -218,12 +202,6 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     const int r = (l & 15) + t;
     return r * V2_DROW + (((l >> 4) ^ (((r >> 1) & 3) << 1)) << 4);
   };
-  auto cross_off = [&](int l, int q) __attribute__((always_inline)) {
-    // (three taps: the fourth K group has zero weights; it reads the rows of tap 2 again, which are real rows of the value)
-    const int rx = (l & 15) + (NTAPS == 3 ? min(l >> 4, 2) : 4 * q + (l >> 4)), px = rx >> 1;
-    const int sx = (((px >> 1) & 1) << 2) | (((px >> 2) & 1) << 1) | (px & 1);
-    return rx * V2_DROW + ((4 ^ sx) << 4);
-  };
 
   // (row c16 + tap of slab buffer `b`, as an offset from the start of the LDS: the buffer bases have bits 4, 5 clear)
   auto cross_at = [&](int l, int base, int tap) __attribute__((always_inline)) {      // base = byte offset of the slab buffer
@@ -231,65 +209,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     const int sx = (((px >> 1) & 1) << 2) | (((px >> 2) & 1) << 1) | (px & 1);
     return base + rx * V2_DROW + ((4 ^ sx) << 4);
   };
-  // ---- a cross sub-phase: term 0 = w_lo6 x a_hi6 (chunks 4, 6), term 1 = w_hi6 x a_lo6 (chunks 5, 7); 16 scaled MFMAs;
-  //      ob = this lane's K group: LDS offset of chunk 4 of its row in tile 0
-  auto x_phase_ob = [&](const XSet& X, int ob, int term) __attribute__((always_inline)) {
-    const char* slab = smem;
-    const int oc = ob ^ (term << 4), ot = ob ^ (32 | (term << 4));
-    v4i fc[NSLOT], ft[NSLOT];             // codes 0-15; {codes 16-23, scale dword (byte 0 hi, byte 1 lo), pad}: read NSLOT - 1 tiles ahead
-    auto rd = [&](int g, int s) __attribute__((always_inline)) {
-      fc[s] = *reinterpret_cast<const v4i*>(slab + oc + g * 2048);
-      ft[s] = *reinterpret_cast<const v4i*>(slab + ot + g * 2048);
-    };
-#pragma unroll
-    for (int g = 0; g < NSLOT - 1; ++g) rd(g, g);
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int s = g % NSLOT;
-      if (g + NSLOT - 1 < 8) rd(g + NSLOT - 1, (g + NSLOT - 1) % NSLOT);
-      const v8i b = __builtin_shufflevector(fc[s], ft[s], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const v8i wa = __builtin_shufflevector(X.c[c], X.t[c], 0, 1, 2, 3, 4, 5, 6, 7);
-        if (term == 0) acc[g][c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, b, acc[g][c], 2, 2, 0, X.t[c][2], 0, ft[s][2]);
-        else           acc[g][c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, b, acc[g][c], 2, 2, 0, X.t[c][2], 1, ft[s][2]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  auto x_phase = [&](const XSet& X, int cb, int q, int term) __attribute__((always_inline)) {
-    x_phase_ob(X, buf_of(cb) * V2_DA_BYTES + cross_off(lane_now(), q), term);
-  };
-  // ---- a main phase: hi * hi of taps tap0 .. tap0 + NT - 1 (NT = 1, 2); 16 MFMAs per tap
-  auto m_phase = [&](const WSet& W, int cb, int tap0, int nt) __attribute__((always_inline)) {
-    const char* slab = smem + buf_of(cb) * V2_DA_BYTES;
-    int of[2];
-    const int l = lane_now();
-#pragma unroll
-    for (int j = 0; j < 2; ++j) of[j] = j < nt ? main_off(l, tap0 + j) : 0;
-    f16x8 fm[NSLOT][2];
-    auto rd = [&](int g, int s) __attribute__((always_inline)) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (j < nt) fm[s][j] = *reinterpret_cast<const f16x8*>(slab + of[j] + g * 2048);
-    };
-#pragma unroll
-    for (int g = 0; g < NSLOT - 1; ++g) rd(g, g);
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int s = g % NSLOT;
-      if (g + NSLOT - 1 < 8) rd(g + NSLOT - 1, (g + NSLOT - 1) % NSLOT);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (j < nt) {
-#pragma unroll
-          for (int c = 0; c < 2; ++c) acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w[j][c], fm[s][j], acc[g][c], 0, 0, 0);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  if constexpr (NTAPS != 5) {
+  {
     // ---- quads of channel blocks on the generated schedule V2Q<NTAPS> (3 taps = the ResNet form: 3 x 3 on the zero-bordered grid
     //      as three taps along time over the 3 C channels of a kernel row)
     using Q = V2Q<NTAPS>;
@@ -311,6 +231,8 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
         }
       }
     };
+    // ---- a cross phase: term 0 = w_lo6 x a_hi6 (chunks 4, 6), term 1 = w_hi6 x a_lo6 (chunks 5, 7); 16 scaled MFMAs;
+    //      ob = this lane's K group: LDS offset of chunk 4 of its row in tile 0; fragments read NSLOT - 1 tiles ahead
     auto x_phase_s = [&](const RSet& X, int ob, int term) __attribute__((always_inline)) {
       const int oc = ob ^ (term << 4), ot = ob ^ (32 | (term << 4));
       v4i fc[NSLOT], ft[NSLOT];
@@ -334,6 +256,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
         __builtin_amdgcn_sched_barrier(0);
       }
     };
+    // ---- a main phase: hi * hi of one or two taps (possibly of neighbouring blocks); 16 MFMAs per tap
     auto m_phase_s = [&](const RSet& W, int cbA, int tapA, int cbB, int tapB, int nt) __attribute__((always_inline)) {
       const char* slab = smem;
       int of[2];
@@ -413,112 +336,6 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     quad(cb_end - 4, std::true_type());
 #pragma unroll
     for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(acc[g][0]), "+v"(acc[g][1]));     // (and again towards the epilogue)
-  } else {
-  XSet XA, XB;
-  WSet WA, WB;
-  // prologue: slab cb_begin; XA, XB = the cross sets of (cb_begin, q 0); 7 taps: WA = taps 0, 1; 5 taps: WB = taps 2, 3
-  for (int g = wave; g < NGRP; g += 4) dma_a(cb_begin, buf_of(cb_begin), g, lane_now());
-  load_x(XA, NTAPS == 5 ? cb_begin >> 1 : cb_begin, 0, 0);
-  load_x(XB, NTAPS == 5 ? cb_begin >> 1 : cb_begin, 0, 1);
-  load_w2(WA, cb_begin, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // VMEM issue order of one channel block (E = issued at the start of the phase) and the count each wait leaves in flight =
-  // the operations issued behind the set it releases:
-  //   7 taps  XA0: slab x5, WB(2,3) x4 | XB0: XA(q1) x4 | M01: XB(q1) x4 | M23: WA(4,5) x4 | XA1: WB(6) x2 | XB1: XA(q0') x4 | M45: XB(q0') x4 | M6: WA(0,1)' x4
-  //   waits   XA0 8    XB0 13 (8) M01 13 (8) M23 8   XA1 8    XB1 6    M45 6 (2)    M6 8 (0)     (the last one stages no slab either)
-  //   (in brackets: the last channel block; the tables of the 3-, 5- and 9-tap bodies stand at their code)
-  // The last channel block issues nothing for a next one, so its final waits count fewer operations: it is a second, straight-line
-  // copy of the body behind the loop (a run-time test inside one body splits it into blocks and costs the register allocation).
-  auto body = [&](int cb, auto last_tag) __attribute__((always_inline)) {
-    constexpr bool last = decltype(last_tag)::value;
-    const int nx = cb + 1;
-    {
-      // 5 taps, a PAIR of channel blocks cb, c1 = cb + 1 per body: the ten taps fill three macro steps (12 K groups) instead of
-      // four (16) -- q0 = taps 0-3 of cb; q1 = tap 4 of cb + taps 0-2 of c1; q2 = taps 3, 4 of c1 + two groups of zero weights (they
-      // read the rows of tap 4 again) -- 128 instead of 144 MFMAs per channel block.  q1 reads both slabs: three slab buffers in a
-      // ring, slab c + 1 still goes out at the top of block c (its buffer held slab c - 2, last read in the block before).
-      //   block A  XA(q0): WB(2,3) x4, slab c1 x5 | XB(q0): XA(q1) x4 | M01: XB(q1) x4 | M23: WA(4) x2 | M4: WB(0,1 c1) x4 | barrier
-      //   block B  XA(q1): WA(2,3 c1) x4, slab x5 | XB(q1): XA(q2) x4 | M01': XB(q2) x4 | M23': WB(4 c1) x2 | XA(q2): WA(0,1)'' x4 |
-      //            XB(q2): XA(q0'') x4 | M4': XB(q0'') x4 | barrier
-      //   waits    A: 4  9  21  8  0      B: 10  15 (10)  13 (8)  8  6  6 (2)  8 (0)       (in brackets: the last pair)
-      const int c1 = cb + 1, k = cb >> 1;
-      // K groups of the three macro steps (selects, not branches: a branch here would split the body into blocks)
-      auto ob0 = [&]() __attribute__((always_inline)) {
-        const int l = lane_now();
-        return cross_at(l, buf_of(cb) * V2_DA_BYTES, l >> 4);
-      };
-      auto ob1 = [&]() __attribute__((always_inline)) {       // group 0: tap 4 of cb; groups 1-3: taps 0-2 of c1
-        const int l = lane_now(), g = l >> 4;
-        const int b0 = buf_of(cb) * V2_DA_BYTES, b1 = buf_of(c1) * V2_DA_BYTES;
-        return cross_at(l, g == 0 ? b0 : b1, g == 0 ? 4 : g - 1);
-      };
-      auto ob2 = [&]() __attribute__((always_inline)) {       // groups 0, 1: taps 3, 4 of c1; groups 2, 3 (zero weights): tap 4 again
-        const int l = lane_now(), g = l >> 4;
-        return cross_at(l, buf_of(c1) * V2_DA_BYTES, g == 0 ? 3 : 4);
-      };
-      V2_WAITX(4, XA);
-      load_w2(WB, cb, 2);
-      dma_next(cb);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase_ob(XA, ob0(), 0);
-      V2_WAITX(9, XB);
-      load_x(XA, k, 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase_ob(XB, ob0(), 1);
-      V2_WAITW2(21, WA);
-      load_x(XB, k, 1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WA, cb, 0, 2);
-      V2_WAITW2(8, WB);                   // (13 would do for WB; 8 also lands slab c1 before the barrier)
-      load_w1(WA, cb, 4);
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WB, cb, 2, 2);
-      V2_WAITW1(0, WA);                   // (tap 4: one main phase of lead, as in the per-block schedule)
-      load_w2(WB, c1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WA, cb, 4, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();                    // slab c1 is visible; (slab cb stays: q1 reads its tap 4)
-      V2_WAITX(10, XA);
-      load_w2(WA, c1, 2);
-      if constexpr (!last) dma_next(c1);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase_ob(XA, ob1(), 0);
-      if constexpr (!last) V2_WAITX(15, XB); else V2_WAITX(10, XB);
-      load_x(XA, k, 2, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase_ob(XB, ob1(), 1);
-      if constexpr (!last) V2_WAITW2(13, WB); else V2_WAITW2(8, WB);
-      load_x(XB, k, 2, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WB, c1, 0, 2);
-      V2_WAITW2(8, WA);
-      load_w1(WB, c1, 4);
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WA, c1, 2, 2);
-      V2_WAITX(6, XA);
-      if constexpr (!last) load_w2(WA, cb + 2, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase_ob(XA, ob2(), 0);
-      if constexpr (!last) { V2_WAITX(6, XB); load_x(XA, k + 1, 0, 0); } else { V2_WAITX(2, XB); }
-      __builtin_amdgcn_sched_barrier(0);
-      x_phase_ob(XB, ob2(), 1);
-      if constexpr (!last) { V2_WAITW1(8, WB); load_x(XB, k + 1, 0, 1); } else { V2_WAITW1(0, WB); }
-      __builtin_amdgcn_sched_barrier(0);
-      m_phase(WB, c1, 4, 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                      // every wave is done reading slab cb; slab cb + 1 landed long ago (waits above)
-  };
-  constexpr int CBS = NTAPS == 5 ? 2 : 1;          // channel blocks per body
-  for (int cb = cb_begin; cb + CBS < cb_end; cb += CBS) body(cb, std::false_type());
-  // (hand-over to the straight-line copy: an empty asm over the accumulators ends their live ranges here, so that the allocator may
-  // re-assign them for the copy instead of spilling one tile across the seam -- it did, in the 5-tap form)
-#pragma unroll
-  for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(acc[g][0]), "+v"(acc[g][1]));
-  body(cb_end - CBS, std::true_type());
   }
   // (nothing is in flight here: the last body waited for its last set with vmcnt(0) and its end-of-block barrier has been passed
   // by every wave, so the slab buffers may become the epilogue's scratch)
@@ -668,9 +485,6 @@ __global__ __launch_bounds__(256) void f6v2_tail_reduce_kernel(GemmArgs p, int m
 }
 
 #undef V2_GLD16
-#undef V2_WAITX
-#undef V2_WAITW2
-#undef V2_WAITW1
 
 // a.Xsb = activations in the two-unit block format (row stride a.ldsbx channels), a.Wfr / a.Wx6 = main / cross weights
 // (xvec_api.hip, upload_layer), a.K = taps * a.cin, taps 5, 7 or 9, a.cin % 32 == 0.  a.tail_mt / a.ksplit / a.partial: the K-split tail
@@ -703,10 +517,9 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
     }
   }
   const int nMt = ((a.M + V2_BM - 1) / V2_BM) * (bins ? a.nbin : 1), nNt = a.Npad / V2_BN, ncb = a.cin >> 5;
-  if (taps == 5 && (ncb & 1)) return hipErrorInvalidValue;      // the 5-tap body takes channel blocks in pairs,
-  if (taps != 5 && (ncb & 3)) return hipErrorInvalidValue;      // the other bodies in quads
+  if (ncb & 3) return hipErrorInvalidValue;      // the bodies take channel blocks in quads
   const bool tail = !bins && a.tail_mt > 0 && (a.ksplit == 2 || a.ksplit == 4 || a.ksplit == 8) && a.partial && a.tail_mt < nMt && ncb % a.ksplit == 0 &&
-                    (ncb / a.ksplit) % (taps == 5 ? 2 : 4) == 0;
+                    (ncb / a.ksplit) % 4 == 0;
   const int nMain = tail ? nMt - a.tail_mt : nMt;
   const int S = tail ? a.ksplit : 0;
   const dim3 grid(nMain * nNt + (tail ? a.tail_mt * nNt * a.ksplit : 0)), block(256);

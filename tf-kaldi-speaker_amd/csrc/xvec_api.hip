@@ -803,22 +803,18 @@ int upload_layer(xv_handle* h, Layer& L) {
     XV_HIP(h, L.wfr.alloc(elems * 4));
     XV_HIP(h, hipMemcpy(L.wfr.p, fr.data(), elems * 4, hipMemcpyHostToDevice));
     if (L.use_f6) {
-      // gemm_f6v2_kernel operands (the scaled weights w * wscale, like the f16 halves above): taps padded with zeros to NQ groups of
-      // four (NQ = 2 for 5 / 7 taps, 3 for 9).
-      //   main  [Npad/32][cin/32][4 NQ taps][2 channel tiles][64 lanes = 16 * k-chunk + channel][8 x f16]
-      //   cross [Npad/32][cin/32][NQ macro steps][2 terms: q6(w - f16(w)), q6(f16(w))][2 channel tiles] x { 64 x 16 B codes 0-15 |
-      //         64 x 16 B {codes 16-23, scale dword (E8M0 in byte 0), pad} },  lane = 16 * (tap & 3) + channel: K group = tap inside the macro step
+      // gemm_f6v2_kernel operands (the scaled weights w * wscale, like the f16 halves above):
+      //   main  [Npad/32][cin/32][4 NQ tap slots, fw used][2 channel tiles][64 lanes = 16 * k-chunk + channel][8 x f16]      (NQ = ceil(fw / 4))
+      //   cross [Npad/32][cin/128][fw macro steps][2 terms: q6(w - f16(w)), q6(f16(w))][2 channel tiles] x { 64 x 16 B codes 0-15 |
+      //         64 x 16 B {codes 16-23, scale dword (E8M0 in byte 0), pad} },  lane = 16 * K group + channel
       // (a 3 x 3 grid convolution = three taps along time over the 3 cin contiguous channels of a kernel row: HWIO k-major is
       //  already [kt][kf * cin + c][n])
       const int fw = L.mode == 1 ? 3 : L.w, fcin = L.mode == 1 ? 3 * L.cin : L.cin;
       const int ncb = fcin / 32, NQ = (fw + 3) / 4;
       const size_t main_ct = 64 * 16, cross_ct = 2 * 64 * 16;
-      // 5 taps: the cross operands are grouped over PAIRS of channel blocks -- slot p = 4 q + g (macro step q < 3, K group g) of pair k
-      // is tap p % 5 of channel block 2 k + p / 5 for p < 10, zero weights for p = 10, 11:  [Npad/32][cin/64][3][2 terms][2 tiles]
-      // 3 taps (ResNet form): over QUADS of channel blocks -- slot p = 3 (cb & 3) + tap, twelve slots = three macro steps exactly
-      // 7 taps: quads as well, 28 slots = seven macro steps
-      const bool pairs = L.mode == 0 && fw == 5, quads = !pairs;
-      const size_t xsteps = pairs ? (size_t)(ncb / 2) * 3 : quads ? (size_t)(ncb / 4) * fw : (size_t)ncb * NQ;
+      // The cross operands are grouped over QUADS of channel blocks: slot p = fw * (cb & 3) + tap of a quad is K group p & 3 of its macro
+      // step p >> 2 -- 4 fw slots = fw macro steps exactly, no zero groups:  [Npad/32][cin/128][fw][2 terms][2 tiles]
+      const size_t xsteps = (size_t)(ncb / 4) * fw;
       std::vector<unsigned char> wm((size_t)(L.Npad / 32) * ncb * (4 * NQ) * 2 * main_ct, 0), wx((size_t)(L.Npad / 32) * xsteps * 2 * 2 * cross_ct, 0);
       for (int n = 0; n < L.Npad; ++n) {
         const int nb = n >> 5, ct = (n >> 4) & 1, r16 = n & 15;
@@ -834,17 +830,9 @@ int upload_layer(xv_handle* h, Layer& L) {
             }
             unsigned char* pm = &wm[((((size_t)nb * ncb + cb) * (4 * NQ) + j) * 2 + ct) * main_ct];
             for (int kc = 0; kc < 4; ++kc) memcpy(pm + (16 * kc + r16) * 16, &hh[8 * kc], 16);
-            int slot = j;                                   // position among the K groups: macro step slot >> 2, group slot & 3
-            size_t xstep = (size_t)cb * NQ + (j >> 2);
-            if (pairs) {
-              if (j >= fw) continue;                        // (the two zero groups of a pair stay zero)
-              slot = (cb & 1) * 5 + j;
-              xstep = (size_t)(cb >> 1) * 3 + (slot >> 2);
-            } else if (quads) {
-              if (j >= fw) continue;
-              slot = (cb & 3) * fw + j;
-              xstep = (size_t)(cb >> 2) * fw + (slot >> 2);
-            }
+            if (j >= fw) continue;                          // (main weights: tap slots padded to 4 NQ; the cross operands have no padding)
+            const int slot = (cb & 3) * fw + j;
+            const size_t xstep = (size_t)(cb >> 2) * fw + (slot >> 2);
             const int ln = 16 * (slot & 3) + r16;
             for (int term = 0; term < 2; ++term) {          // term 0 multiplies q6(hi) of the activations, term 1 q6(lo)
               unsigned char* px = &wx[(((((size_t)nb * xsteps + xstep) * 2 + term) * 2) + ct) * cross_ct];
@@ -974,7 +962,7 @@ int xv_finalize(xv_handle* h) {
       // two-unit split: the 5-, 7- and 9-tap layers over whole 32-channel blocks (the first layer, K = 5 x 30, stays on the f16 kernel and writes
       // the block format of its reader: gemm_bf16x3_w14p2_kernel<1, 3, true>)
       L.use_f6 = h->desc.precision == XV_PREC_F16F6 && L.use_split && !L.im2col && (L.w == 5 || L.w == 7 || L.w == 9) &&
-                 L.cin % (L.w == 5 ? 64 : 128) == 0 && L.cout % 4 == 0;      // (5 taps: channel blocks in pairs, 7 / 9: in quads)
+                 L.cin % 128 == 0 && L.cout % 4 == 0;      // (the kernel takes channel blocks in quads)
     } else {      // grid convolutions: whole SB blocks per tap; conv0 goes through its own im2col
       L.use_split = bf && (L.mode == 4 || L.cin % 32 == 0);
       // two-unit split of the stride-1 3 x 3 convolutions: three taps along time over the 3 C channels of a kernel row
@@ -1340,7 +1328,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
       } else if (L.use_f6) {
         scratch = (st.rows_in + kSlackRows) * (int64_t)sb_ld(L.cin) * 4;      // the input in the block format of gemm_f16f6.hip
         if (h->opt_tail_split && op.in1 <= 0 && L.mode == 0) {
-          const int64_t part = gemm_bf16x3_tail_plan(st.M, L.Kpad, L.Npad, L.w, &st.tail_mt, &st.ksplit, L.w == 5 ? 2 : 4);
+          const int64_t part = gemm_bf16x3_tail_plan(st.M, L.Kpad, L.Npad, L.w, &st.tail_mt, &st.ksplit, 4);
           if (part > 0) {
             step_scratch2 = align_up(part, kAlign);
             st.scratch2_off = arena_alloc(step_scratch2);
