@@ -20,9 +20,9 @@ PARTS = {
     "f16f6": [
         ("im2col_sb_kernel", 1228800, None, "tdnn1_conv"),                                           # feature rows -> SB rows (staging of L1)
         ("w14p2_kernel", 614400, None, "tdnn1_conv"),                                                # L1 on the f16 kernel, F6-output epilogue
-        ("gemm_f6v2_kernel<5", 655360, None, "tdnn2_conv"),                                          # whole tiles + K-split tail slices
-        ("gemm_f6v2_kernel<7", 655360, None, "tdnn3_conv"),
-        ("f6v2_tail_reduce_kernel", 32768, None, "tdnn2_conv"), ("f6v2_tail_reduce_kernel", 16384, None, "tdnn3_conv"),
+        ("gemm_f6v2_kernel<5", None, None, "tdnn2_conv"),                                            # whole tiles + K-split tail slices (any grid)
+        ("gemm_f6v2_kernel<7", None, None, "tdnn3_conv"),
+        ("f6v2_tail_reduce_kernel", 262144, None, "tdnn2_conv"), ("f6v2_tail_reduce_kernel", 131072, None, "tdnn3_conv"),
         ("w1p3_kernel", 585728, None, "tdnn4_dense"), ("w1p3_kernel", 1757184, None, "tdnn5_dense"),
     ],
 }
@@ -35,7 +35,7 @@ def read(path, counter, parts):
         if m:
             cur = None
             for sub, grid, idx, layer in parts:
-                if sub in m.group(1) and int(m.group(3)) == grid and \
+                if sub in m.group(1) and (grid is None or int(m.group(3)) == grid) and \
                         (idx is None or (m.group(2) is not None and int(m.group(2)) == idx)):
                     cur = layer
             continue

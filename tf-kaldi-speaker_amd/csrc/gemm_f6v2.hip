@@ -1,31 +1,36 @@
-// Two-unit split-precision GEMM for the 5- and 7-tap temporal convolutions (XV_PREC_F16F6), second schedule: three workgroups
-// per CU, every load two phases ahead of its use, counted waits only.  The arithmetic is that of gemm_f16f6.hip:
+// Two-unit split-precision GEMM (XV_PREC_F16F6) for the 5-, 7- and 9-tap temporal convolutions of the (extended) TDNN and, as a
+// three-tap form, the stride-1 3 x 3 convolutions of the ResNet stages.  Three workgroups per CU, every load two or three phases
+// ahead of its use, counted waits only.  The arithmetic:
 //
 //   a * w ~ f16(a) * f16(w)                                                   v_mfma_f32_16x16x32_f16
 //         + q6(f16(a)) * q6(w - f16(w)) + q6(a - f16(a)) * q6(f16(w))          2 x v_mfma_scale_f32_16x16x128_f8f6f4 (e2m3, E8M0 block scale)
 //
-// and so are the activation block format (gemm_f16f6.hip; chunks 6 / 7 = [8 B code tail | scale dword | pad] of q6(hi) / q6(lo)),
-// the slab staging by LDS-DMA and the 128 x 128 workgroup tile of four waves, each wave one 32-channel block x 128 frames.
+// Activations in the block format of gemm_f16f6.hip (128 B per (row, 32 channels): f16 hi | fp6 codes of hi and lo | chunks 6 / 7 =
+// [8 B code tail | scale dword | pad] of q6(hi) / q6(lo)), staged slab by slab (128 frames + halo x 32 channels) by LDS-DMA; 128 x 128
+// workgroup tile of four waves, each wave one 32-channel block x 128 frames (64 accumulator registers); weights from L2 straight
+// into registers in MFMA-fragment order.
 //
-// What is different -- and why.  The first schedule held the main weights of two macro steps (64 registers) plus the cross weights
-// (26) and ran at 250 VGPRs = two workgroups per CU, with one full vmcnt(0) drain per macro step; the counters said the matrix pipe
-// was busy 54 % of the time, the LDS 36 % (bank conflicts removed: no change -- it was never the LDS), i.e. two waves per SIMD do
-// not cover the waits, and 2 336 tiles on 512 slots are 4.56 rounds.  Here a channel block is EIGHT PHASES, each with its own
-// small weight set, loaded while the two phases before it run into registers the phase before those has just released:
+// The K = 128 of a scaled MFMA is four "K groups" of 32 channels; a K group is one (channel block, tap) pair -- lane group l >> 4 reads
+// slab row frame + tap of its pair's block.  Pairs are enumerated block-major across a QUAD of channel blocks: 4 T pairs = T macro
+// steps exactly, whatever T (one block at a time would need ceil(T / 4) steps per block with zero-weight groups in the last: 25 %
+// more cross MFMAs for T = 3 and 9, 60 % for T = 5, 14 % for T = 7).  A macro step then spans at most two neighbouring blocks; it
+// runs during the later one, with both slabs resident: three slab buffers in a ring (52 KB, still three workgroups per CU), slab
+// c + 1 issued at the top of block c into the buffer slab c - 2 left at the barrier before.
 //
-//   7 taps   XA0  XB0  M01  M23  XA1  XB1  M45  M6          XA / XB: the cross terms of a macro step q (four taps) as two
-//   5 taps   XA0  XB0  M01  M23  XA1  XB1  M4                        sub-phases -- w_lo6 x a_hi6, then w_hi6 x a_lo6 -- of 16 scaled MFMAs:
-//                                                                    one 16-register weight set and one 8-register fragment each;
-//                                                           Mjk:     hi * hi of taps j, k: 16 weight registers, 32 MFMAs.
-//
-// Register sets XA, XB, WA, WB of 16 registers each = 64 instead of 90, which with the
-// 64 accumulators and the fragments fits the 168 registers of three workgroups per CU (768 slots: 3.04 rounds, and the K-split tail
-// of gemm_bf16x3.hip for the rest).  Every set is issued at the START of the phase after its last reader and consumed two or three
-// phases later (48 - 80 MFMAs = 0.8 - 1.3 k cycles of this wave, three times that in wall time with three waves per SIMD); the waits
-// are exact vmcnt(N) counts of the younger operations (table at the loop), never a drain.  The slab of the next channel block (five
-// LDS-DMA pieces per wave) goes out right behind the workgroup barrier and has the whole channel block to land.
+// A quad is a list of PHASES (V2Q<T>::ph below): a cross phase = one term of a macro step (16 scaled MFMAs, one 16-register operand
+// set), a main phase = hi * hi of one or two taps (16 / 32 MFMAs, 8 / 16 registers).  Sets rotate: the set a phase has consumed is
+// reloaded at the start of the next phase for the phase NS - 1 further on, so every load has NS - 1 phases (32 - 96 MFMAs of this
+// wave, three times that in wall time) to land, and every s_waitcnt vmcnt(N) is computed from the table at compile time (v2q_wait:
+// the loads and LDS-DMA pieces issued behind the awaited set) -- no hand-counted tables, no drain.  NS = 3 sets (48 registers) for 5,
+// 7, 9 taps, 4 for the short three-tap body; with the accumulators and two fragment slots 164 - 168 VGPRs.  The last quad of a tile
+// is a second, straight-line copy that issues nothing for a next one (a run-time test inside the body would split it into blocks
+// and cost the register allocation); per-lane LDS / DMA offsets are recomputed from the lane id per phase (selects, never
+// branches) instead of living in loop-invariant registers.  History: round 2 ran two macro steps of main weights + cross weights
+// at 250 VGPRs = two workgroups per CU with a vmcnt(0) drain per macro step (54 % matrix-pipe busy); round 3 first hand-scheduled
+// eight phases per channel block on four named sets (63 %), then this generated form, which removed the zero K groups.
 #include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "xv_f6.h"
 

@@ -1,4 +1,4 @@
-# Collect the round's evidence on the GPU box: bench lines (default bf16x3 + exact f32 + the other configs),
+# Collect the round's evidence on the GPU box: bench lines (default f16f6, bf16x3, exact f32, the other configs),
 # rocprofv3 kernel trace/stats of the same command, PMC passes (separate runs, kernel-trace only).
 # usage: bash tools/profile_round.sh <tag>    -> gpurun_out/<tag>/
 tag=${1:-r03}
@@ -13,14 +13,16 @@ step att; python bench.py --pooling self_attention --cpu-seconds 0 --no-extra > 
 python bench.py --pooling self_attention --precision bf16x3 --cpu-seconds 0 --no-extra > $out/bench_att_bf16x3.json 2>> $out/bench_att.err
 step varlen; python bench.py --varlen --cpu-seconds 0 --no-extra > $out/bench_varlen_f16f6.json 2> $out/bench_varlen.err
 python bench.py --varlen --precision bf16x3 --cpu-seconds 0 --no-extra > $out/bench_varlen_bf16x3.json 2>> $out/bench_varlen.err
-step etdnn; python bench.py --network extended_tdnn --cpu-seconds 0 --no-extra > $out/bench_etdnn_bf16x3.json 2> $out/bench_etdnn.err
-python bench.py --network extended_tdnn --precision f16f6 --cpu-seconds 0 --no-extra > $out/bench_etdnn_f16f6.json 2>> $out/bench_etdnn.err
-step resnet; python bench.py --network resnet_18 --batch 64 --dim 40 --cpu-seconds 4 --no-extra > $out/bench_resnet18_bf16x3.json 2> $out/bench_resnet.err
+step etdnn; python bench.py --network extended_tdnn --precision bf16x3 --cpu-seconds 0 --no-extra > $out/bench_etdnn_bf16x3.json 2> $out/bench_etdnn.err
+python bench.py --network extended_tdnn --cpu-seconds 0 --no-extra > $out/bench_etdnn_f16f6.json 2>> $out/bench_etdnn.err
+step resnet; python bench.py --network resnet_18 --batch 64 --dim 40 --cpu-seconds 4 --no-extra > $out/bench_resnet18_f16f6.json 2> $out/bench_resnet.err
+python bench.py --network resnet_18 --batch 64 --dim 40 --precision bf16x3 --cpu-seconds 0 --no-extra > $out/bench_resnet18_bf16x3.json 2>> $out/bench_resnet.err
 step f16; python bench.py --precision f16x3 --cpu-seconds 0 --no-extra > $out/bench_f16x3.json 2> $out/bench_f16x3.err
 step att_f16; python bench.py --pooling self_attention --precision f16x3 --cpu-seconds 0 --no-extra > $out/bench_att_f16x3.json 2> $out/bench_att_f16.err
 step ab; python tools/ab_options.py tail_split tdnn 2>&1 | grep -v amdgpu.ids > $out/ab_tail_split.txt 2>&1
 python tools/reader_rate.py 100000 /tmp 2>&1 | grep -v amdgpu.ids > $out/reader_rate.txt
 for p in f16f6 bf16x3; do python tools/layer_times.py tdnn $p 2>&1 | grep -v amdgpu.ids | tail -2; done > $out/layer_times.txt 2>&1
+for n in etdnn resnet; do for p in f16f6 bf16x3; do echo "$n $p"; LT_MAX=60 python tools/layer_times.py $n $p 2>&1 | grep -v amdgpu.ids | tail -1; done; done >> $out/layer_times.txt 2>&1
 step cli; python tools/cli_throughput.py 100000 2>&1 | grep -v amdgpu.ids > $out/cli_throughput.txt; python tools/cli_throughput.py 300000 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt; python tools/cli_throughput.py 150000 --varlen 2>&1 | grep -v amdgpu.ids >> $out/cli_throughput.txt
 step host; python tools/host_profile.py 100000 2>&1 | grep -v amdgpu.ids > $out/host_profile.txt; python tools/pipeline_probe.py 2>&1 | grep -v amdgpu.ids > $out/pipeline_probe.txt
 step trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --cpu-seconds 0 --no-extra > $out/trace.log 2>&1
