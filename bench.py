@@ -515,7 +515,7 @@ def main():
             if precision == "f16f6" and dom["name"].endswith("_conv"):
                 roof["mfma_issue_frac"] = round(1.5 * tf / peak, 4)
                 roof["note"] = ("two-unit split: hi*hi on the f16 MFMA + two cross terms on the block-scaled fp6 MFMA (4x rate) = 1.5 f16 "
-                                "MFMA units per algorithmic product (plus the zero-weight taps of a padded group), so the ceiling of "
+                                "MFMA units per algorithmic product (K groups formed over quads of channel blocks: no zero-weight groups), so the ceiling of "
                                 "`frac` is 2/3; mfma_issue_frac = those units / f16 dense peak")
             elif precision != "f32":
                 roof["mfma_issue_frac"] = round(3 * tf / peak, 4)

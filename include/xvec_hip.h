@@ -70,10 +70,11 @@ enum {
                           are pre-scaled per layer by a power of two into the fp16 range (undone in the epilogue);
                           activations / input features beyond +-65504 overflow to inf -- outputs are then non-finite and
                           the host mirror raises instead of returning them */
-  XV_PREC_F16F6 = 3    /* f16x3 everywhere except the multi-tap temporal convolutions (4..8 taps, whole 32-channel blocks),
-                          which compute hi*hi on v_mfma_f32_16x16x32_f16 and the two cross terms on the block-scaled fp6
-                          path (v_mfma_scale_f32_16x16x128_f8f6f4, e2m3, one scale per 32 channels): 1.5 MFMA units per
-                          product instead of 3, ~1e-5 relative on the x-vector (bar 1e-4).  Same range rule as f16x3. */
+  XV_PREC_F16F6 = 3    /* f16x3 everywhere except the 5- / 7- / 9-tap temporal convolutions (input channels a multiple of 128)
+                          and the stride-1 3x3 ResNet convolutions of >= 128 channels (multiples of 128), which compute hi*hi
+                          on v_mfma_f32_16x16x32_f16 and the two cross terms on the block-scaled fp6 path
+                          (v_mfma_scale_f32_16x16x128_f8f6f4, e2m3, one scale per 32 channels): 1.5 MFMA units per product
+                          instead of 3, ~2e-6 relative on the x-vector (bar 1e-4).  Same range rule as f16x3. */
 };
 
 #define XV_MAX_ATT_LAYERS 4
@@ -151,6 +152,9 @@ int xv_finalize(xv_handle* h);
  * switch them off to prove which path ran.  "att_fusion" (default 1): attention scores / weighted moments computed in
  * the epilogues of the last key layer / the value layer instead of from stored activations; "slab3" (default 1): one-tap
  * layers on the kernel with three activation-slab buffers (0: the two-buffer kernel, bit-identical results).
+ * "grid_compact" (default 1): ResNet convolutions enumerate output bins only (0: every grid position, bit-identical);
+ * "grid_f6" (default 1; set before xv_finalize, it decides the weight formats): XV_PREC_F16F6 runs the eligible ResNet
+ * convolutions on the two-unit kernel (0: on the f16x3 kernels).
  * "profile_dominant" (default 0): xv_profile_* brackets only the step
  * with the most algorithmic FLOPs of each plan (two events per forward instead of two per kernel). */
 int xv_set_option(xv_handle* h, const char* name, int value);
