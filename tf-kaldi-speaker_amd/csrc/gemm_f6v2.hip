@@ -128,6 +128,44 @@ template <class Q> constexpr int v2q_wait_slab(int iend, bool last) {
     if (v2q_has_set<Q>(j, last)) n += v2q_loads<Q>(j + Q::NS - 1);
   return n;
 }
+// A table is complete and consistent: every (block, tap) of the quad in exactly one main phase, every (macro step, term) in exactly
+// one cross phase -- in the block that holds the last of its four pairs --, a phase only touches the block it runs in or the one
+// before (the two resident slabs), blocks in order, and the phase count a multiple of the set count (the rotation closes).
+template <class Q> constexpr bool v2q_valid(int T) {
+  if (Q::NPH % Q::NS != 0 || Q::NX != T) return false;
+  for (int b = 0; b < 4; ++b)
+    for (int t = 0; t < T; ++t) {
+      int n = 0;
+      for (int i = 0; i < Q::NPH; ++i) {
+        const V2Phase& p = Q::ph[i];
+        if (p.kind != 0) continue;
+        if (p.a == b && p.b == t) ++n;
+        if (p.c == b && p.d == t) ++n;
+      }
+      if (n != 1) return false;
+    }
+  for (int q = 0; q < T; ++q)
+    for (int term = 0; term < 2; ++term) {
+      int n = 0;
+      for (int i = 0; i < Q::NPH; ++i) {
+        const V2Phase& p = Q::ph[i];
+        if (p.kind == 1 && p.a == q && p.b == term) { ++n; if (p.blk != (4 * q + 3) / T) return false; }
+      }
+      if (n != 1) return false;
+    }
+  for (int i = 0; i < Q::NPH; ++i) {
+    const V2Phase& p = Q::ph[i];
+    if (p.blk < 0 || p.blk > 3 || (i > 0 && p.blk < Q::ph[i - 1].blk)) return false;
+    if (p.kind == 0) {
+      if (p.a != p.blk && p.a != p.blk - 1) return false;
+      if (p.c >= 0 && p.c != p.blk && p.c != p.blk - 1) return false;
+      if (p.a < 0 || p.b < 0 || p.b >= T || (p.c >= 0 && (p.d < 0 || p.d >= T))) return false;
+    }
+  }
+  return true;
+}
+static_assert(v2q_valid<V2Q<3>>(3) && v2q_valid<V2Q<5>>(5) && v2q_valid<V2Q<7>>(7) && v2q_valid<V2Q<9>>(9), "phase table");
+
 template <class F, int... I>
 __device__ __forceinline__ void v2q_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>()), ...); }
 
