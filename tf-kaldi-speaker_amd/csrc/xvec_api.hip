@@ -150,6 +150,7 @@ struct xv_handle {
   // options (xv_set_option)
   int opt_pool_fusion = 1;                            // statistics pooling fused into the last frame layer's epilogue
   int opt_tail_split = 1;                             // K-split of the last, nearly empty round of GEMM tiles
+  int opt_onetap_f6_notail = 1;                       // (A/B switch of the note in xv_plan_create)
   int opt_grid_f6 = 1;                                // XV_PREC_F16F6: the stride-1 3 x 3 ResNet convolutions of >= 128 channels on the two-unit kernel
   int opt_slab3 = 1;                                  // one-tap GEMM layers on the three-slab-buffer kernel
   int opt_grid_compact = 1;                           // ResNet grid convolutions enumerate output bins only (split precisions)
@@ -1032,6 +1033,7 @@ int xv_set_option(xv_handle* h, const char* name, int value) {
   else if (!strcmp(name, "tail_split")) h->opt_tail_split = value != 0;
   else if (!strcmp(name, "att_fusion")) h->opt_att_fusion = value != 0;
   else if (!strcmp(name, "slab3")) h->opt_slab3 = value != 0;
+  else if (!strcmp(name, "onetap_f6_notail")) h->opt_onetap_f6_notail = value != 0;
   else if (!strcmp(name, "grid_f6")) h->opt_grid_f6 = value != 0;      // (before xv_finalize: it decides the weight formats)
   else if (!strcmp(name, "grid_compact")) h->opt_grid_compact = value != 0;
   else if (!strcmp(name, "profile_dominant")) h->opt_profile_dominant = value != 0;
@@ -1474,6 +1476,10 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     }
     prod->out_f6 = true;
     cs.in_f6 = true;
+    // a one-tap producer keeps the three-slab kernel for all its tiles: its K-split tail (raw slices of the two-slab kernel + the
+    // block-format reduce) costs more than the third of a round it saves (extended TDNN in-process A/B: 2.192 -> 2.172 ms,
+    // profiles/r03/ab_onetap_f6_notail.txt)
+    if (!grid && PL.mode == 0 && !PL.use_f6 && PL.w == 1 && h->opt_onetap_f6_notail) { prod->tail_mt = 0; prod->ksplit = 1; }
   }
 
   // output shape

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """In-process A/B of library options (xv_set_option): interleaved rounds of K forwards per setting, median ms per forward.
-usage: python tools/ab_options.py <option> [tdnn|att|resnet] [precision]     e.g.  python tools/ab_options.py slab3 att"""
+usage: python tools/ab_options.py <option> [tdnn|att|etdnn|resnet] [precision]     e.g.  python tools/ab_options.py slab3 att"""
 import os
 import sys
 import time
@@ -20,7 +20,10 @@ if net == "resnet":
     params, dim, B, T = Params(**dict(synth.RESNET_PARAMS)), 40, 64, 300
     weights = synth.synth_resnet_weights(params, seed=0)
 else:
-    params = Params(**dict(synth.TDNN_ATT_PARAMS if net == "att" else synth.TDNN_STAT_PARAMS))
+    base = dict(synth.TDNN_ATT_PARAMS if net == "att" else synth.TDNN_STAT_PARAMS)
+    if net == "etdnn":
+        base.update(network_type="extended_tdnn", embedding_node="tdnn12_dense")
+    params = Params(**base)
     dim, B, T = 30, 256, 300
     weights = synth.synth_weights(params, dim, seed=0)
 feats = torch.from_numpy(np.concatenate(synth.synth_features(B, T, dim, seed=3))).cuda()
