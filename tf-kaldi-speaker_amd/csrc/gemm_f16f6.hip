@@ -13,9 +13,9 @@
 //   chunk 6 / 7 bytes 16-23 of the codes of q6(hi) / q6(lo) | one dword {byte 0: E8M0 scale of q6(hi), byte 1: of q6(lo)} | 4 bytes pad
 // so that the operand of one cross sub-phase (codes + scale of one of the two quantised halves) is two 16-byte reads.  One lane's
 // operand of the scaled MFMA is such a block: lane l holds row / column l & 15 and K group l >> 4 = 32 consecutive K elements, 32 x 6
-// bits little-endian, scale per lane (checked bit-exactly: tools/mfma_scale_probe.hip).  The K = 128 of a scaled MFMA is "four taps of
-// one channel block": group g reads slab row frame + 4q + g -- the rows the four main MFMAs of those taps read.  Taps beyond the
-// layer's width have zero weights in the cross operands and are skipped in the main pass.
+// bits little-endian, scale per lane (checked bit-exactly: tools/mfma_scale_probe.hip).  The K = 128 of a scaled MFMA is four K
+// groups, each one (channel block, tap) pair of a quad of channel blocks: a group reads slab row frame + tap of its block -- the rows
+// the main MFMA of that tap reads (gemm_f6v2.hip).
 #include "xv_f6.h"
 
 namespace xv {

@@ -45,8 +45,7 @@ typedef __attribute__((address_space(3))) void* lptr2_t;
 constexpr int V2_BM = 128, V2_BN = 128, V2_DROW = 128;
 // slab rows: 128 frames + the halo of the last tap (a K group of the cross terms reads row frame + its tap, like the main pass), in
 // whole 8-row DMA pieces: 136 rows for up to nine taps
-constexpr int v2_groups(int ntaps) { return ntaps <= 9 ? 17 : 18; }
-constexpr int v2_slab_bytes(int ntaps) { return v2_groups(ntaps) * 8 * V2_DROW; }
+constexpr int kV2Groups = 17, kV2SlabBytes = kV2Groups * 8 * V2_DROW, kV2Ring = 3;      // 17 408 B per slab, 52 224 B of LDS
 constexpr int64_t kMainCt = 64 * 16;               // bytes per (tap, 16-channel tile) of the main weights: 64 lanes x 16 B
 constexpr int64_t kXCt = 2 * 64 * 16;              // per (macro step, term, 16-channel tile) of the cross weights: 64 x 16 B codes 0-15 |
                                                    // 64 x 16 B {codes 16-23, scale dword, pad}: one lane offset serves both planes
@@ -175,10 +174,10 @@ __device__ __forceinline__ void v2q_for(F&& f, std::integer_sequence<int, I...>)
 template <int NTAPS, bool OUT_F6, bool RES>
 __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, char* smem, int cb_begin, int cb_end, bool slice, int bin = 0) {
   static_assert(NTAPS == 3 || NTAPS == 5 || NTAPS == 7 || NTAPS == 9, "taps");
-  constexpr int NQ = (NTAPS + 3) / 4;    // macro steps (groups of four taps) per channel block
-  constexpr int NGRP = v2_groups(NTAPS), V2_DA_BYTES = v2_slab_bytes(NTAPS);
+  constexpr int NQ = (NTAPS + 3) / 4;    // (the main weights are stored in 4 NQ tap slots per channel block)
+  constexpr int NGRP = kV2Groups, V2_DA_BYTES = kV2SlabBytes;
   constexpr int NSLOT = 2;               // fragment slots per phase: tile g + 1 is read while tile g multiplies
-  constexpr int RING = 3;                // slab buffers: a macro step spans two channel blocks, both stay resident
+  constexpr int RING = kV2Ring;          // slab buffers: a macro step spans two channel blocks, both stay resident
   const int tid = threadIdx.x;
   int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,7 +212,7 @@ __device__ __forceinline__ void f6v2_tile(const GemmArgs& p, int m0, int n0, cha
     const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + buf * V2_DA_BYTES + g * 1024);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory");
   };
-  auto buf_of = [&](int cb) __attribute__((always_inline)) { return RING == 3 ? cb % 3 : cb & 1; };
+  auto buf_of = [&](int cb) __attribute__((always_inline)) { return cb % RING; };
   auto dma_next = [&](int cb) __attribute__((always_inline)) {  // slab cb + 1: five pieces per wave (17 groups, the last ones duplicates)
     const int nx = cb + 1;
     const int l = lane_now();
@@ -542,7 +541,7 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   static std::mutex mu;
   static bool attr_set[64] = {};
-  const size_t smem = (size_t)3 * v2_slab_bytes(taps);
+  const size_t smem = (size_t)kV2Ring * kV2SlabBytes;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   {
@@ -553,7 +552,7 @@ hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s) {
                           reinterpret_cast<const void*>(gemm_f6v2_kernel<9, false>), reinterpret_cast<const void*>(gemm_f6v2_kernel<9, true>),
                           reinterpret_cast<const void*>(gemm_f6v2_kernel<3, true>), reinterpret_cast<const void*>(gemm_f6v2_kernel<3, true, true>)};
       for (const void* k : ks) {
-        const hipError_t r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * v2_slab_bytes(5));
+        const hipError_t r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kV2Ring * kV2SlabBytes);
         if (r != hipSuccess) return r;
       }
       attr_set[dev & 63] = true;
