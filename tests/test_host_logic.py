@@ -229,4 +229,3 @@ def test_asm_guard_catches_an_in_flight_register_and_a_compiler_load(repo_root):
         rows = [l for l in open(rep) if l.startswith("_Z")]
         assert len(rows) >= 20 and all(l.rstrip().endswith("violations 0") for l in rows)
         assert sum("gemm_f6v2_kernel" in l and "all-paths" in l for l in rows) == 8      # 5, 7, 9 taps x two output formats + the two ResNet forms
-        assert sum("gemm_f6d_kernel" in l and "all-paths" in l for l in rows) == 4       # the dense form: four epilogues

@@ -527,215 +527,6 @@ __global__ __launch_bounds__(256) void f6v2_tail_reduce_kernel(GemmArgs p, int m
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// One-tap (dense) layers on the two-unit split.  A dense layer has no taps to fill the four K groups of a scaled MFMA with: they are
-// four CHANNEL BLOCKS of the same 128 rows, so a macro step needs four 16 KB slabs resident, and a prefetched quad four more:
-// 128 KB of LDS = one workgroup per CU.  Hence EIGHT waves per workgroup and a 128 x 256 tile (wave w: channels n0 + 32 w .. + 31 of
-// all 128 rows; the slabs are shared by eight waves instead of four, which also halves their traffic per MFMA): two waves per SIMD,
-// up to 256 registers each.  A quad of channel blocks is four phases -- cross term 0, cross term 1 (16 scaled MFMAs each), hi * hi
-// of blocks 0, 1 and of blocks 2, 3 (32 MFMAs each): 96 MFMAs per 128 channels of K instead of the 192 of the three-unit kernel --
-// on four register sets whose rotation closes with the quad (each set always serves the same phase); the slabs of quad q + 1 (eight
-// LDS-DMA pieces per wave) go out at the top of quad q, behind the one workgroup barrier per quad.  Issue order and waits:
-//   P0 (X term 0): set M23 x4, slabs x8 | P1 (X term 1): set X0' x4 | P2 (M01): set X1' x4 | P3 (M23): set M01' x4 | vmcnt(12), barrier
-//   waits  P0 8   P1 16 (8)   P2 16 (4)   P3 16 (0)      (in brackets: the last quad, which issues nothing for a next one)
-constexpr int kDSlabBytes = 16 * 8 * V2_DROW, kDRing = 8;       // 16 KB per slab, two quads of slabs = 128 KB
-
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm_f6d_kernel(GemmArgs p, int nMt, int nNt) {
-  extern __shared__ __attribute__((aligned(16))) char smem_d[];
-  char* smem = smem_d;
-  constexpr int NSLOT = 2;
-  const int tile = xcd_remap(blockIdx.x, nMt * nNt);
-  const int mt = tile / nNt, nt = tile - mt * nNt;
-  const int m0 = mt * V2_BM, n0 = nt * 256;
-  const int tid = threadIdx.x;
-  int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ncb = p.cin >> 5;
-  const int64_t a_row_bytes = p.ldsbx * 4;
-  const uint32_t as_lds = (uint32_t)(uintptr_t)(lptr2_t)smem;
-  const char* Abase = reinterpret_cast<const char*>(p.Xsb) + (int64_t)m0 * a_row_bytes;
-  auto lane_now = [&]() __attribute__((always_inline)) {
-    asm volatile("" : "+v"(lane));
-    return lane;
-  };
-  // (slab swizzle and DMA piece addressing as in f6v2_tile)
-  auto dma_a = [&](int cb, int g, int l) {
-    const int lr = l >> 3, lp = l & 7;
-    const int s1 = ((lr >> 1) & 3) << 1;
-    const int s2 = (((lr >> 2) & 1) << 2) | ((lr >> 1) & 1) | ((g & 1) << 1);
-    const int c = lp ^ ((((lp >> 2) ^ (lr >> 2)) & 1) ? s2 : s1);
-    const uint32_t off = (uint32_t)lr * (uint32_t)a_row_bytes + (uint32_t)(c << 4);
-    const char* base = Abase + (int64_t)(8 * g) * a_row_bytes + (int64_t)cb * 128;
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(as_lds + (cb & (kDRing - 1)) * kDSlabBytes + g * 1024);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory");
-  };
-  auto dma_quad = [&](int cbq) __attribute__((always_inline)) {      // the four slabs of the quad at cbq: pieces wave, wave + 8 of each
-    const int l = lane_now();
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      dma_a(cbq + c, wave, l);
-      dma_a(cbq + c, wave + 8, l);
-    }
-  };
-  const int nb = (n0 >> 5) + wave;
-  const bool active = n0 + wave * 32 < p.Npad;                    // (the last 256-channel tile of an Npad = 128 (mod 256) layer)
-  const int nbw = active ? nb : (n0 >> 5);
-  const char* Wm = reinterpret_cast<const char*>(p.Wfr) + (int64_t)nbw * ncb * 8 * kMainCt;          // [cb][4 tap slots][2 tiles][1 KB], tap 0 used
-  const char* Wx = reinterpret_cast<const char*>(p.Wx6) + (int64_t)nbw * (ncb >> 2) * 4 * kXCt;      // [quad][term][2 tiles][2 KB]
-  struct RSet { v4i r[4]; };
-  RSet S0, S1, S2, S3;                                            // X term 0, X term 1, M(blocks 0, 1), M(blocks 2, 3)
-  auto load_x = [&](RSet& R, int cbq, int term) __attribute__((always_inline)) {
-    const int voA = lane_now() << 4;
-    const char* b = Wx + (((int64_t)(cbq >> 2) * 2 + term) * 2) * kXCt;
-    V2_GLD16(R.r[0], voA, b, 0); V2_GLD16(R.r[1], voA, b, 1024);
-    V2_GLD16(R.r[2], voA, b, 2048); V2_GLD16(R.r[3], voA, b, 3072);
-  };
-  auto load_m = [&](RSet& R, int cb) __attribute__((always_inline)) {      // tap 0 of blocks cb, cb + 1
-    const int voA = lane_now() << 4;
-    const char* b = Wm + (int64_t)cb * 8 * kMainCt;
-    const char* b2 = b + 8 * kMainCt;
-    V2_GLD16(R.r[0], voA, b, 0); V2_GLD16(R.r[1], voA, b, 1024);
-    V2_GLD16(R.r[2], voA, b2, 0); V2_GLD16(R.r[3], voA, b2, 1024);
-  };
-  f32x4 acc[8][2];
-#pragma unroll
-  for (int g = 0; g < 8; ++g)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto x_phase = [&](const RSet& X, int cbq, int term) __attribute__((always_inline)) {
-    // K group g4 = channel block cbq + g4: row c16 of its slab, chunk 4 ^ f2(row)
-    const int l = lane_now();
-    const int rx = l & 15, px = rx >> 1;
-    const int sx = (((px >> 1) & 1) << 2) | (((px >> 2) & 1) << 1) | (px & 1);
-    const int ob = (((cbq + (l >> 4)) & (kDRing - 1)) * kDSlabBytes) + rx * V2_DROW + ((4 ^ sx) << 4);
-    const int oc = ob ^ (term << 4), ot = ob ^ (32 | (term << 4));
-    v4i fc[NSLOT], ft[NSLOT];
-    auto rd = [&](int g, int s) __attribute__((always_inline)) {
-      fc[s] = *reinterpret_cast<const v4i*>(smem + oc + g * 2048);
-      ft[s] = *reinterpret_cast<const v4i*>(smem + ot + g * 2048);
-    };
-#pragma unroll
-    for (int g = 0; g < NSLOT - 1; ++g) rd(g, g);
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int s = g % NSLOT;
-      if (g + NSLOT - 1 < 8) rd(g + NSLOT - 1, (g + NSLOT - 1) % NSLOT);
-      const v8i b = __builtin_shufflevector(fc[s], ft[s], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const v8i wa = __builtin_shufflevector(X.r[2 * c], X.r[2 * c + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-        if (term == 0) acc[g][c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, b, acc[g][c], 2, 2, 0, X.r[2 * c + 1][2], 0, ft[s][2]);
-        else           acc[g][c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, b, acc[g][c], 2, 2, 0, X.r[2 * c + 1][2], 1, ft[s][2]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  auto m_phase = [&](const RSet& W, int cb) __attribute__((always_inline)) {       // hi * hi of blocks cb, cb + 1
-    const int l = lane_now();
-    const int r = l & 15;
-    const int o = r * V2_DROW + (((l >> 4) ^ (((r >> 1) & 3) << 1)) << 4);
-    const int of0 = (cb & (kDRing - 1)) * kDSlabBytes + o, of1 = ((cb + 1) & (kDRing - 1)) * kDSlabBytes + o;
-    f16x8 fm[NSLOT][2];
-    auto rd = [&](int g, int s) __attribute__((always_inline)) {
-      fm[s][0] = *reinterpret_cast<const f16x8*>(smem + of0 + g * 2048);
-      fm[s][1] = *reinterpret_cast<const f16x8*>(smem + of1 + g * 2048);
-    };
-#pragma unroll
-    for (int g = 0; g < NSLOT - 1; ++g) rd(g, g);
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int s = g % NSLOT;
-      if (g + NSLOT - 1 < 8) rd(g + NSLOT - 1, (g + NSLOT - 1) % NSLOT);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-          acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W.r[2 * j + c]), fm[s][j], acc[g][c], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-#define V2D_WAIT(N, R) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(R.r[0]), "+v"(R.r[1]), "+v"(R.r[2]), "+v"(R.r[3]))
-  // prologue: the slabs of quad 0, the sets of its first three phases
-  dma_quad(0);
-  load_x(S0, 0, 0);
-  load_x(S1, 0, 1);
-  load_m(S2, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  auto quad = [&](int cbq, auto last_tag) __attribute__((always_inline)) {
-    constexpr bool last = decltype(last_tag)::value;
-    V2D_WAIT(8, S0);
-    load_m(S3, cbq + 2);
-    if constexpr (!last) dma_quad(cbq + 4);
-    __builtin_amdgcn_sched_barrier(0);
-    x_phase(S0, cbq, 0);
-    if constexpr (!last) { V2D_WAIT(16, S1); load_x(S0, cbq + 4, 0); } else { V2D_WAIT(8, S1); }
-    __builtin_amdgcn_sched_barrier(0);
-    x_phase(S1, cbq, 1);
-    if constexpr (!last) { V2D_WAIT(16, S2); load_x(S1, cbq + 4, 1); } else { V2D_WAIT(4, S2); }
-    __builtin_amdgcn_sched_barrier(0);
-    m_phase(S2, cbq);
-    if constexpr (!last) { V2D_WAIT(16, S3); load_m(S2, cbq + 4); } else { V2D_WAIT(0, S3); }
-    __builtin_amdgcn_sched_barrier(0);
-    m_phase(S3, cbq + 2);
-    if constexpr (!last) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // the next quad's slabs have landed (behind them: three sets)
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-  };
-  for (int cb = 0; cb + 4 < ncb; cb += 4) quad(cb, std::false_type());
-#pragma unroll
-  for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(acc[g][0]), "+v"(acc[g][1]));
-  quad(ncb - 4, std::true_type());
-#undef V2D_WAIT
-  __builtin_amdgcn_sched_barrier(0);
-  int lane_e = lane;
-  asm volatile("" : "+v"(lane_e));
-  if (!active) return;                     // (no barrier behind this point: the epilogue scratch is private to a wave)
-  if constexpr (EPI == 3) store_wave_tile_n32_f6(p, acc, m0, n0 + wave * 32, lane_e, wave, smem);
-  else if constexpr (EPI != 0) store_wave_tile_n32_att<EPI>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem);
-  else store_wave_tile_n32<64, true>(p, acc, m0, n0 + wave * 32, lane_e, wave, smem);
-}
-
-// a.Xsb = activations in the block format (row stride a.ldsbx = a.cin channels), a.Wfr / a.Wx6 = main / cross weights of a one-tap
-// layer (xvec_api.hip, upload_layer: fw = 1), a.cin % 128 == 0.  Epilogue by the fields of `a`: attention forms (att_part / pool_w),
-// block format (ysb_f6), or the standard one (fp32 / split-blocked / fused statistics pooling).
-hipError_t launch_gemm_f6d(const GemmArgs& a, hipStream_t s) {
-  if (a.M <= 0) return hipSuccess;
-  if (a.K != a.cin || (a.cin & 127) || a.ldsbx != a.cin || !a.Wx6 || !a.Wfr || a.a_pitch || a.R || a.rowmap || (a.N & 3) || (a.Npad & 127))
-    return hipErrorInvalidValue;
-  static std::mutex mu;
-  static bool attr_set[64] = {};
-  const size_t smem = (size_t)kDRing * kDSlabBytes;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  {
-    std::lock_guard<std::mutex> lock(mu);
-    if (!attr_set[dev & 63]) {
-      const void* ks[] = {reinterpret_cast<const void*>(gemm_f6d_kernel<0>), reinterpret_cast<const void*>(gemm_f6d_kernel<1>),
-                          reinterpret_cast<const void*>(gemm_f6d_kernel<2>), reinterpret_cast<const void*>(gemm_f6d_kernel<3>)};
-      for (const void* k : ks) {
-        const hipError_t r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (r != hipSuccess) return r;
-      }
-      attr_set[dev & 63] = true;
-    }
-  }
-  const int nMt = (a.M + V2_BM - 1) / V2_BM, nNt = (a.Npad + 255) / 256;
-  const dim3 grid(nMt * nNt), block(512);
-  if (a.att_part || a.pool_w) {
-    if ((a.pool_w && !a.pool_part)) return hipErrorInvalidValue;
-    if (a.att_part) hipLaunchKernelGGL(gemm_f6d_kernel<1>, grid, block, smem, s, a, nMt, nNt);
-    else            hipLaunchKernelGGL(gemm_f6d_kernel<2>, grid, block, smem, s, a, nMt, nNt);
-  } else if (a.ysb_f6) {
-    if (!a.Ysb || a.Y || a.pool_part) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gemm_f6d_kernel<3>, grid, block, smem, s, a, nMt, nNt);
-  } else {
-    hipLaunchKernelGGL(gemm_f6d_kernel<0>, grid, block, smem, s, a, nMt, nNt);
-  }
-  return hipGetLastError();
-}
-
 #undef V2_GLD16
 
 // a.Xsb = activations in the two-unit block format (row stride a.ldsbx channels), a.Wfr / a.Wx6 = main / cross weights

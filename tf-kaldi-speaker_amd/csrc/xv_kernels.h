@@ -135,8 +135,6 @@ hipError_t launch_im2col_sb(const float* x, int64_t ldx, int cin, int w, int64_t
 hipError_t launch_gemm_bf16x3(const GemmArgs& a, hipStream_t s);
 // two-unit split of the multi-tap convolutions (XV_PREC_F16F6: f16 hi*hi + two block-scaled fp6 cross terms), gemm_f16f6.hip
 hipError_t launch_gemm_f16f6(const GemmArgs& a, hipStream_t s);
-// two-unit split of a one-tap (dense) layer: eight waves, 128 x 256 tile, one workgroup per CU (gemm_f6v2.hip)
-hipError_t launch_gemm_f6d(const GemmArgs& a, hipStream_t s);
 // reduce of a K-split tail whose slices hold raw sums (a.partial / a.tail_mt / a.ksplit in {2, 4, 8}; rows from M tile nMain on):
 // BN scale / shift + activation, then the split-blocked rows or (a.ysb_f6) the two-unit block format
 hipError_t launch_f6v2_tail_reduce(const GemmArgs& a, int nMain, hipStream_t s);

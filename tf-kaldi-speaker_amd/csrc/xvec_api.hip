@@ -150,7 +150,6 @@ struct xv_handle {
   // options (xv_set_option)
   int opt_pool_fusion = 1;                            // statistics pooling fused into the last frame layer's epilogue
   int opt_tail_split = 1;                             // K-split of the last, nearly empty round of GEMM tiles
-  int opt_dense_f6 = 1;                               // XV_PREC_F16F6: frame-level dense layers on the two-unit kernel (set before xv_finalize)
   int opt_onetap_f6_notail = 1;                       // (A/B switch of the note in xv_plan_create)
   int opt_grid_f6 = 1;                                // XV_PREC_F16F6: the stride-1 3 x 3 ResNet convolutions of >= 128 channels on the two-unit kernel
   int opt_slab3 = 1;                                  // one-tap GEMM layers on the three-slab-buffer kernel
@@ -963,9 +962,10 @@ int xv_finalize(xv_handle* h) {
       L.use_split = L.im2col || (bf && vin.frame_level && (L.w == 1 || (L.cin % 32 == 0 && L.w <= 9)));   // slab halo of the split kernel
       // two-unit split: the 5-, 7- and 9-tap layers over whole 32-channel blocks (the first layer, K = 5 x 30, stays on the f16 kernel and writes
       // the block format of its reader: gemm_bf16x3_w14p2_kernel<1, 3, true>)
-      L.use_f6 = h->desc.precision == XV_PREC_F16F6 && L.use_split && !L.im2col &&
-                 (L.w == 5 || L.w == 7 || L.w == 9 || (L.w == 1 && h->opt_dense_f6)) &&
-                 L.cin % 128 == 0 && L.cout % 4 == 0;      // (the kernels take channel blocks in quads; one tap: gemm_f6d_kernel)
+      // (dense layers stay on three units: a one-tap two-unit kernel needs four slabs per macro step = one workgroup per CU, and
+      //  with nothing to overlap its prologue and epilogue it was no faster -- profiles/r03/ab_dense_two_unit.txt)
+      L.use_f6 = h->desc.precision == XV_PREC_F16F6 && L.use_split && !L.im2col && (L.w == 5 || L.w == 7 || L.w == 9) &&
+                 L.cin % 128 == 0 && L.cout % 4 == 0;      // (the kernel takes channel blocks in quads)
     } else {      // grid convolutions: whole SB blocks per tap; conv0 goes through its own im2col
       L.use_split = bf && (L.mode == 4 || L.cin % 32 == 0);
       // two-unit split of the stride-1 3 x 3 convolutions: three taps along time over the 3 C channels of a kernel row
@@ -1035,7 +1035,6 @@ int xv_set_option(xv_handle* h, const char* name, int value) {
   else if (!strcmp(name, "tail_split")) h->opt_tail_split = value != 0;
   else if (!strcmp(name, "att_fusion")) h->opt_att_fusion = value != 0;
   else if (!strcmp(name, "slab3")) h->opt_slab3 = value != 0;
-  else if (!strcmp(name, "dense_f6")) h->opt_dense_f6 = value != 0;
   else if (!strcmp(name, "onetap_f6_notail")) h->opt_onetap_f6_notail = value != 0;
   else if (!strcmp(name, "grid_f6")) h->opt_grid_f6 = value != 0;      // (before xv_finalize: it decides the weight formats)
   else if (!strcmp(name, "grid_compact")) h->opt_grid_compact = value != 0;
@@ -1332,7 +1331,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
         if (st.ksplit > 1) scratch = (int64_t)st.ksplit * st.M * L.Npad * 4;
       } else if (L.use_f6) {
         scratch = (st.rows_in + kSlackRows) * (int64_t)sb_ld(L.cin) * 4;      // the input in the block format of gemm_f16f6.hip
-        if (h->opt_tail_split && op.in1 <= 0 && L.mode == 0 && L.w > 1) {
+        if (h->opt_tail_split && op.in1 <= 0 && L.mode == 0) {
           const int64_t part = gemm_bf16x3_tail_plan(st.M, L.Kpad, L.Npad, L.w, &st.tail_mt, &st.ksplit, 4);
           if (part > 0) {
             step_scratch2 = align_up(part, kAlign);
@@ -1452,8 +1451,7 @@ int xv_plan_create(xv_handle* h, const int32_t* frame_offsets, int batch, int no
     const bool grid = h->layers[cop.layer].mode == 1;
     // readers of the value's SPLIT copy: every op that takes it as its first input; a second input is the fp32 residual of a ResNet
     // block (another copy of the value) -- in the TDNN graphs it does not occur, and disqualifies as before
-    // Several readers are fine when every one of them is a two-unit layer (the attention config: tdnn4_relu feeds the key network
-    // and tdnn5).
+    // Several readers are fine when every one of them is a two-unit layer.
     if (cs.in_f6) continue;                // (marked with an earlier reader of the same value)
     int readers = 0;
     bool all_f6 = true;
@@ -1847,8 +1845,7 @@ static int run_plan(xv_handle* h, const xv_plan* p, const float* feats, int feat
             a.ksplit = st.ksplit;
             a.partial = reinterpret_cast<float*>(ws + st.scratch2_off);
           }
-          if (L.mode == 0 && L.w == 1) XV_HIP(h, launch_gemm_f6d(a, s));
-          else XV_HIP(h, launch_gemm_f16f6(a, s));
+          XV_HIP(h, launch_gemm_f16f6(a, s));
           if (st.unpad_to_out)
             XV_HIP(h, launch_grid_unpad_n(reinterpret_cast<const float*>(ws + st.out_off), off_out, B, vo.grid_F, vo.grid_S, vo.cols,
                                           st.frames_out, out, s));
