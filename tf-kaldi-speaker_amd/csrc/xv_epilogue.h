@@ -594,6 +594,49 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
   if (p.Y || (ROWS == 64 && p.pool_part)) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
+      if (ROWS == 64 && p.pool_part && !p.Y) {
+        // Fused statistics pooling, the usual pass (all 64 frames of one utterance: 3.5 passes of 4.5 at 286 frames): straight from
+        // the accumulators.  A lane holds 8 channels (2 tiles x 4) of the four frames c16 + 16 fl; the 16 lanes of a DPP row hold the
+        // 16 frames of a tile row, so a channel's sum over the pass is four adds in-lane and a four-step butterfly across the row
+        // (quad_perm, quad_perm, row_half_mirror, row_mirror: no LDS, no wait).  Same partials as the staged form below -- (sum, M2
+        // about the pass mean) per (utterance, 64-frame tile) slot -- in another summation order.
+        const int mb = mbase + ps * 64;
+        const int my_utt = (mb + lane < p.M) ? p.pool_row2utt[mb + lane] : -1;
+        const int u_first = __builtin_amdgcn_readlane(my_utt, 0), u_last = __builtin_amdgcn_readlane(my_utt, 63);
+        if (u_first >= 0 && u_first == u_last) {
+          auto row_sum = [&](float x) -> float {
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // row_mirror
+            return x;
+          };
+          const int64_t slot = (int64_t)p.pool_slotbase[u_first] + (mb >> 6);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            f32x4 s1 = z;
+#pragma unroll
+            for (int fl = 0; fl < FPP; ++fl) s1 += value4(acc[ps * FPP + fl][ct], ct, false);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s1[i] = row_sum(s1[i]);
+            const f32x4 mu = s1 * (1.0f / 64.0f);
+            f32x4 m2 = z;
+#pragma unroll
+            for (int fl = 0; fl < FPP; ++fl) {
+              const f32x4 d = value4(acc[ps * FPP + fl][ct], ct, false) - mu;
+              m2 += d * d;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m2[i] = row_sum(m2[i]);
+            const int nn = nbase + 16 * ct + 4 * g4;
+            if (c16 == 0 && nn < p.N) {
+              *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2) * p.N + nn) = s1;
+              *reinterpret_cast<f32x4*>(p.pool_part + (slot * 2 + 1) * p.N + nn) = m2;
+            }
+          }
+          continue;
+        }
+      }
       stage_f32(ps, false);
       wave_lds_sync();
       if (ps == 0) XV_EPI_STAMP(p, 6);
