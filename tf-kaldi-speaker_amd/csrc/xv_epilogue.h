@@ -514,7 +514,6 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
 #pragma unroll 2
       for (int it = 0; it < ROWS / 8; ++it) {
         const int row = it * 8 + rrow;
-        const int m = mbase + ps * ROWS + row;
         f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ swz8(row)) << 4));
         bool zero;
         const int orow = out_row_pre(ps, it, zero);
@@ -576,7 +575,6 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
 #pragma unroll 4
       for (int it = 0; it < ROWS / 8; ++it) {
         const int row = it * 8 + rrow;
-        const int m = mbase + ps * ROWS + row;
         f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ swz8(row)) << 4));
         bool zero;
         const int orow = out_row_pre(ps, it, zero);
@@ -644,7 +642,6 @@ __device__ __forceinline__ void store_wave_tile_n32_impl(const GemmArgs& p, cons
 #pragma unroll 4
         for (int it = 0; it < ROWS / 8; ++it) {
           const int row = it * 8 + rrow;
-          const int m = mbase + ps * ROWS + row;
           f32x4 v = *reinterpret_cast<const f32x4*>(scratch + row * 128 + ((rchunk ^ swz8(row)) << 4));
           bool zero;
           const int orow = out_row_pre(ps, it, zero);
