@@ -26,10 +26,10 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def _trainer(params, weights, dim, precision):
+def _trainer(params, weights, dim, precision, **kw):
     from tf_kaldi_speaker_amd.params import Params
     from tf_kaldi_speaker_amd.trainer import Trainer
-    tr = Trainer(Params(**dict(params)), None, dim, single_cpu=True, device=0, precision=precision)
+    tr = Trainer(Params(**dict(params)), None, dim, single_cpu=True, device=0, precision=precision, **kw)
     tr.build("predict")
     tr.load_weights(weights)
     return tr
@@ -299,7 +299,7 @@ def test_f16x3_is_tighter_than_bf16x3_and_reports_overflow():
     feats = np.stack(utts)
     res = {}
     for prec in ("f32", "bf16x3", "f16x3"):
-        tr = _trainer(params, weights, 30, prec)
+        tr = _trainer(params, weights, 30, prec, range_fallback=False)
         res[prec] = {}
         for node in ("attention_weights", "tdnn6_dense"):
             tr.set_embedding(node)
@@ -378,11 +378,24 @@ def test_fp16_split_refuses_features_it_cannot_represent():
     feats = np.stack(synth.synth_features(2, 40, 30, seed=9))
     tiny = (feats * 2.0 ** -14).astype(np.float32)
     for prec in ("f16x3", "f16f6"):
-        tr = _trainer(params, weights, 30, prec)
+        tr = _trainer(params, weights, 30, prec, range_fallback=False)
         with pytest.raises(FloatingPointError, match="below 2\\^-8"):
             tr.predict(tiny)
         ok = tr.predict(feats)                                              # the flag was reset: the next batch is fine
         assert _rel(ok[0], ref_numpy.predict(feats[0], weights, params, 30)) <= TOL
+        tr.close()
+        # the default: the refused batch runs on a bf16x3 twin of the model instead (the reference accepts any finite features);
+        # batches inside the range stay on the fast path, bit-identical to a trainer without the twin
+        tr = _trainer(params, weights, 30, prec)
+        with pytest.warns(UserWarning, match="bf16x3"):
+            got = tr.predict(tiny)
+        assert _rel(got[1], ref_numpy.predict(tiny[1], weights, params, 30)) <= TOL
+        assert np.array_equal(tr.predict(feats), ok)
+        huge = feats.copy()
+        huge[1, 7, 3] = 1.0e5
+        got = tr.predict_list([huge[0], huge[1]])                          # the pipelined interface: collect() re-runs the batch
+        assert _rel(got[1], ref_numpy.predict(huge[1], weights, params, 30)) <= TOL
+        assert np.array_equal(tr.predict_list([feats[0], feats[1]]), ok)
         tr.close()
     tr = _trainer(params, weights, 30, "bf16x3")
     got = tr.predict(tiny)
@@ -428,7 +441,7 @@ def test_pipelined_host_interface_equals_blocking_calls():
     weights = synth.synth_weights(params, 30, seed=0)
     rs = np.random.RandomState(4)
     batches = [synth.synth_features(n, [int(t) for t in rs.randint(15, 400, size=n)], 30, seed=60 + n) for n in (5, 64, 1, 17, 33, 9)]
-    tr = _trainer(params, weights, 30, "f16f6")
+    tr = _trainer(params, weights, 30, "f16f6", range_fallback=False)
     want = [tr.predict_list(b) for b in batches]
     got, tickets = [], []
     for b in batches:

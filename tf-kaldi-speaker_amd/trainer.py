@@ -58,7 +58,7 @@ class Trainer(object):
     """Predict-only counterpart of model/trainer.py `Trainer`."""
 
     def __init__(self, params, model_dir, dim, num_speakers=None, single_cpu=False, num_gpus=1,
-                 device=None, precision=None):
+                 device=None, precision=None, range_fallback=None):
         # model/trainer.py:100-110 network dispatch.  Only the TDNN is on this round's hot path.
         self.network_type = params.network_type
         if params.network_type not in _NETWORK_TYPES:
@@ -76,6 +76,15 @@ class Trainer(object):
         self._precision = precision or os.environ.get("XVEC_PRECISION") or default_precision(params.network_type)
         if self._precision not in _PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
+        # The reference (fp32 TensorFlow) accepts any finite features.  The fp16 precisions refuse batches outside their range; with
+        # range_fallback (default on; XVEC_RANGE_FALLBACK=0 or range_fallback=False turn it off) predict / predict_list / collect
+        # then run THAT batch again on a bf16x3 twin of this model (built on first need) instead of raising.
+        if range_fallback is None:
+            range_fallback = os.environ.get("XVEC_RANGE_FALLBACK", "1") != "0"
+        self._range_fallback = bool(range_fallback) and self._precision in _F16_RANGE
+        self._fallback = None
+        self._weights_host = None
+        self._single_cpu = single_cpu
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
         self._device_index = int(device)
@@ -224,6 +233,7 @@ class Trainer(object):
             raise
         self._unused_variables = unused
         self._step = step
+        self._weights_host = weights if self._range_fallback else None
         self.is_loaded = True
 
     # ------------------------------------------------------------------ device-level predict
@@ -397,6 +407,22 @@ class Trainer(object):
         self.raise_on_flags(self.check_overflow(), emb)
         return emb
 
+    def _fallback_trainer(self, why):
+        """The bf16x3 twin for batches the fp16 precisions refuse (full fp32 exponent range, same weights, same node)."""
+        if self._fallback is None:
+            import warnings
+            warnings.warn("%s -- running such batches in bf16x3 (Trainer(range_fallback=False) raises instead)" % why)
+            fb = Trainer(self.params, None, self.dim, single_cpu=self._single_cpu, device=self._device_index, precision="bf16x3",
+                         range_fallback=False)
+            fb.model = self.model
+            fb.build("predict")
+            for name, value in self._options.items():
+                fb.set_option(name, value)
+            fb.load_weights(self._weights_host, self._step)
+            self._fallback = fb
+        self._fallback.embeddings = self.embeddings
+        return self._fallback
+
     def _lazy_load(self):
         # model/trainer.py:891-895
         if self.model is not None and os.path.isfile(os.path.join(self.model, "checkpoint")):
@@ -429,7 +455,12 @@ class Trainer(object):
             node = self.embeddings
             out = self.predict_packed(dev, offsets, node)
             _, info = self._plan(offsets, node)
-            emb = self._checked(out.cpu().numpy())
+            try:
+                emb = self._checked(out.cpu().numpy())
+            except FloatingPointError as e:
+                if not self._range_fallback:
+                    raise
+                emb = self._fallback_trainer(str(e)).predict_packed(dev, offsets, node).cpu().numpy()
         if node == "attention_weights":
             emb = emb.reshape(b, -1, emb.shape[-1])
         elif info.frame_level and emb.shape[0] > b * t:       # ResNet block output [b, l, f, c] (test-only nodes)
@@ -527,7 +558,14 @@ class Trainer(object):
         sl["done"].synchronize()
         sl["busy"] = False
         emb = host_out.numpy().copy()                   # the slot is reused by the next submit
-        self.raise_on_flags(self.decode_flags(sl["flags"]), emb)
+        try:
+            self.raise_on_flags(self.decode_flags(sl["flags"]), emb)
+        except FloatingPointError as e:
+            if not self._range_fallback:
+                raise
+            offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+            with self._torch.cuda.device(self._device_index):      # (the slot's device copy of the batch is intact until the next submit)
+                emb = self._fallback_trainer(str(e)).predict_packed(sl["dev"][:total], offsets, node).cpu().numpy()
         if node == "attention_weights" or not frame_level:
             return emb
         ctx = (total - emb.shape[0]) // len(lens)
@@ -548,6 +586,9 @@ class Trainer(object):
             if self._h is not None:
                 self._lib.xv_destroy(self._h)
                 self._h = None
+        if getattr(self, "_fallback", None) is not None:
+            self._fallback.close()
+            self._fallback = None
         self._ws = None
         self._pinned = None
         self._slots = None
