@@ -30,7 +30,8 @@ def default_precision(network_type):
     """What Trainer, the command-line drivers and bench.py run when no precision is named: f16f6 for every network -- the fastest
     precision, under the same GPU parity suite as the others (tests/test_gpu_parity.py: every endpoint of the three networks,
     both poolings, ragged batches, the rescaled-layer and feature-range tests), with both ends of the fp16 range guarded (values
-    beyond +-65504 and feature batches below 2^-8 raise FloatingPointError instead of producing wrong vectors).  Its two-unit
+    beyond +-65504 and feature batches below 2^-8 never produce wrong vectors: Trainer runs such a batch again in bf16x3, the
+    command-line driver stops with FloatingPointError).  Its two-unit
     kernel covers the 5 / 7 / 9-tap convolutions of the (extended) TDNN and the stride-1 3 x 3 convolutions of the ResNet stages of
     128 channels and more; "bf16x3" (full fp32 exponent range, no such refusals) stays one argument away."""
     return "f16f6" if network_type in ("tdnn", "extended_tdnn", "resnet_18") else DEFAULT_PRECISION
