@@ -50,6 +50,41 @@ def test_extract_cli_matches_oracle(tmp_path, repo_root, normalize):
         assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 1e-4, k
 
 
+def test_extract_cli_reruns_a_batch_outside_the_fp16_range(tmp_path, repo_root):
+    """Default precision (f16f6), several batches in flight, one utterance with a feature of 1e5 (beyond the fp16 range) in the
+    middle and one whose features are all below 2^-8: the reference accepts any finite features, so the driver runs the batches
+    that hold them again on the bf16x3 twin and every vector still meets the parity bar, in order."""
+    from tf_kaldi_speaker_amd import kaldi_io, model_io, synth
+    params = dict(synth.TDNN_STAT_PARAMS, num_nodes_pooling_layer=160, num_nodes_last_layer=48)
+    weights = synth.synth_weights(params, 30, seed=3, channels=128)
+    model_dir = str(tmp_path / "exp")
+    model_io.save_model(model_dir, params, 30, weights, step=1)
+    lens = [40, 55, 70, 33, 90, 64, 48, 77, 52, 61, 45, 80]
+    utts = synth.synth_features(len(lens), lens, 30, seed=21)
+    utts[5][10, 3] = 1.0e5
+    utts[9] = (utts[9] * 2.0 ** -14).astype(np.float32)
+    ark = str(tmp_path / "feats.ark")
+    with open(ark, "wb") as f:
+        for i, u in enumerate(utts):
+            kaldi_io.write_mat(f, u, key="utt%02d" % i)
+    out = str(tmp_path / "xvector.ark")
+    cmd = [sys.executable, "-m", "tf_kaldi_speaker_amd.extract", "--gpu", "0", "--node", "tdnn6_dense", "--batch-frames", "130",
+           model_dir, "ark:%s" % ark, "ark:%s" % out]
+    env = dict(os.environ, PYTHONPATH=repo_root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("XVEC_PRECISION", None)
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "bf16x3" in r.stderr                                        # the warning that names the reason
+    got = list(kaldi_io.read_vec_flt_ark(out))
+    assert [k for k, _ in got] == ["utt%02d" % i for i in range(len(lens))]
+    for (k, a), u in zip(got, utts):
+        b = ref_numpy.predict(u, weights, params, 30)
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 1e-4, k
+    # and without the fallback the driver stops with the message
+    r = subprocess.run(cmd, env=dict(env, XVEC_RANGE_FALLBACK="0"), cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "fp16 range" in r.stderr
+
+
 def test_scp_rspecifier_is_refused(tmp_path, repo_root):
     """extract.py:59-61."""
     from tf_kaldi_speaker_amd import model_io, synth

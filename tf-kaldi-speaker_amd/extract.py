@@ -287,9 +287,10 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
                     return
                 if werr:
                     continue                            # drain after a failure: the main thread raises it
-                keys_p, host_p, flags_p = item
-                emb = host_p.numpy()
-                trainer.raise_on_flags(trainer.decode_flags(flags_p), emb)
+                keys_p, host_p, flags_p, dev_p, offs_p = item
+                # (a batch the fp16 precisions refuse runs again on the bf16x3 twin: its device copy is intact -- the main thread
+                #  cannot reach the turn that reuses the slot before this batch has left the queue)
+                emb = trainer.checked_or_rerun(host_p.numpy(), dev_p, offs_p, code=trainer.decode_flags(flags_p))
                 if normalize:
                     emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
                 writer.write(keys_p, emb)
@@ -307,13 +308,13 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
     def flush(keep=0):
         nonlocal done
         while len(pending) > keep:
-            keys_p, host_p, flags_p, ev = pending.pop(0)
+            keys_p, host_p, flags_p, ev, dev_p, offs_p = pending.pop(0)
             t0 = time.perf_counter()
             ev.synchronize()
             t1 = time.perf_counter()
             if werr:
                 raise werr[0]
-            wq.put((keys_p, host_p, flags_p))           # blocks while the writer is a batch behind: its slots stay untouched
+            wq.put((keys_p, host_p, flags_p, dev_p, offs_p))      # blocks while the writer is a batch behind: its slots stay untouched
             waited["device"] += t1 - t0
             waited["writer"] += time.perf_counter() - t1
             done += len(keys_p)
@@ -358,7 +359,7 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
                     feats = dev.cpu().numpy()
                 else:
                     with torch.cuda.device(dev_index):
-                        emb = trainer._checked(trainer.predict_packed(dev, offsets).cpu().numpy())
+                        emb = trainer.checked_or_rerun(trainer.predict_packed(dev, offsets).cpu().numpy(), dev, offsets)
                     if normalize:
                         emb = emb / np.sqrt(np.sum(np.square(emb), axis=1, keepdims=True))
                     writer.write(keys, emb)
@@ -401,7 +402,7 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
                 ev.record(comp)
                 slot_done[k] = ev
             turn += 1
-            pending.append((list(keys), host_out, flag_pins[k], ev))
+            pending.append((list(keys), host_out, flag_pins[k], ev, dev_in[k][:host.shape[0]], np.array(offsets, dtype=np.int32)))
             flush(keep=KEEP)                                # hand batch i - 2 to the writer while the device runs i - 1 and i
         flush()
     finally:

@@ -30,8 +30,7 @@ def default_precision(network_type):
     """What Trainer, the command-line drivers and bench.py run when no precision is named: f16f6 for every network -- the fastest
     precision, under the same GPU parity suite as the others (tests/test_gpu_parity.py: every endpoint of the three networks,
     both poolings, ragged batches, the rescaled-layer and feature-range tests), with both ends of the fp16 range guarded (values
-    beyond +-65504 and feature batches below 2^-8 never produce wrong vectors: Trainer runs such a batch again in bf16x3, the
-    command-line driver stops with FloatingPointError).  Its two-unit
+    beyond +-65504 and feature batches below 2^-8 never produce wrong vectors: Trainer and the command-line driver run such a batch again in bf16x3).  Its two-unit
     kernel covers the 5 / 7 / 9-tap convolutions of the (extended) TDNN and the stride-1 3 x 3 convolutions of the ResNet stages of
     128 channels and more; "bf16x3" (full fp32 exponent range, no such refusals) stays one argument away."""
     return "f16f6" if network_type in ("tdnn", "extended_tdnn", "resnet_18") else DEFAULT_PRECISION
@@ -424,6 +423,19 @@ class Trainer(object):
         self._fallback.embeddings = self.embeddings
         return self._fallback
 
+    def checked_or_rerun(self, emb, feats_dev, offsets, node=None, code=None):
+        """`emb` = the fetched result of predict_packed(feats_dev, offsets, node): returned as it is when the range guard is clean
+        (`code`: already decoded flags of that forward, else the handle's flag is read), else the same batch from the bf16x3 twin
+        (or the FloatingPointError, without range_fallback)."""
+        try:
+            self.raise_on_flags(self.check_overflow() if code is None else code, emb)
+            return emb
+        except FloatingPointError as e:
+            if not self._range_fallback:
+                raise
+            with self._torch.cuda.device(self._device_index):
+                return self._fallback_trainer(str(e)).predict_packed(feats_dev, offsets, node).cpu().numpy()
+
     def _lazy_load(self):
         # model/trainer.py:891-895
         if self.model is not None and os.path.isfile(os.path.join(self.model, "checkpoint")):
@@ -456,12 +468,7 @@ class Trainer(object):
             node = self.embeddings
             out = self.predict_packed(dev, offsets, node)
             _, info = self._plan(offsets, node)
-            try:
-                emb = self._checked(out.cpu().numpy())
-            except FloatingPointError as e:
-                if not self._range_fallback:
-                    raise
-                emb = self._fallback_trainer(str(e)).predict_packed(dev, offsets, node).cpu().numpy()
+            emb = self.checked_or_rerun(out.cpu().numpy(), dev, offsets, node)
         if node == "attention_weights":
             emb = emb.reshape(b, -1, emb.shape[-1])
         elif info.frame_level and emb.shape[0] > b * t:       # ResNet block output [b, l, f, c] (test-only nodes)
@@ -559,14 +566,9 @@ class Trainer(object):
         sl["done"].synchronize()
         sl["busy"] = False
         emb = host_out.numpy().copy()                   # the slot is reused by the next submit
-        try:
-            self.raise_on_flags(self.decode_flags(sl["flags"]), emb)
-        except FloatingPointError as e:
-            if not self._range_fallback:
-                raise
-            offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-            with self._torch.cuda.device(self._device_index):      # (the slot's device copy of the batch is intact until the next submit)
-                emb = self._fallback_trainer(str(e)).predict_packed(sl["dev"][:total], offsets, node).cpu().numpy()
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        # (the slot's device copy of the batch is intact until the next submit)
+        emb = self.checked_or_rerun(emb, sl["dev"][:total], offsets, node, code=self.decode_flags(sl["flags"]))
         if node == "attention_weights" or not frame_level:
             return emb
         ctx = (total - emb.shape[0]) // len(lens)
