@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Stress the default (bf16x3) kernels over random batch geometries against the exact fp32-MFMA path of the same
+"""Stress the fast kernels (argument 3: f16f6 = the default precision, or bf16x3) over random batch geometries against the exact fp32-MFMA path of the same
 library (itself checked against the oracle by tests/): embeddings must agree to 1e-4 relative L2, repeated runs of one
 geometry must be bit-identical.  Product code only (no oracle).  usage: python tools/stress_shapes.py [cases] [seed]"""
 import os
