@@ -247,9 +247,9 @@ def test_f16f6_two_unit_split(net):
     (csrc/gemm_f6v2.hip: 1.5 MFMA units per product instead of 3).  tests/analysis/f16f8_error_model.py predicts ~1e-5 on the x-vector;
     the bar is the path's 1e-4 against the float64 oracle, on every stage endpoint of the converted layers (their conv / bn
     stages run through the same kernel with other epilogue vectors) and on the embedding; against the exact fp32 path the
-    frame-level layers must stay within 5e-5.  Ragged batch with the shortest possible utterance; narrow variant: 64 channels
-    (two channel blocks, N below the tile); extended TDNN: 5-, 5-, 7- and 9-tap layers (three macro steps of four taps in the last one,
-    behind a one-tap dense layer whose split-blocked output goes through the conversion pass).  Deterministic."""
+    frame-level layers must stay within 5e-5.  Ragged batch with the shortest possible utterance; 64 channels: no quad of channel
+    blocks, the layers fall back to the f16x3 kernels; 128 channels: exactly one quad (the peeled last body alone); extended TDNN:
+    5-, 5-, 7- and 9-tap layers behind one-tap dense layers that write the block format themselves.  Deterministic."""
     from oracle import ref_numpy
     from tf_kaldi_speaker_amd import synth
     import torch
