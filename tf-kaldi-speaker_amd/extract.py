@@ -247,8 +247,10 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
     code on views of the same buffers (in order: everything in flight is written first)."""
     import queue
     import threading
+    import time
     import torch
     from . import native_ark
+    t_enter = time.perf_counter()
     cap = (batch_frames + 65536) * 64
     NPIN, NSLOT, KEEP = 6, 5, 2
     # six staging buffers: the reader is at most two batches ahead (one being filled, one queued), three are in flight on the
@@ -302,7 +304,6 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
     wthread = threading.Thread(target=consumer, daemon=True)
     wthread.start()
 
-    import time
     waited = {"reader": 0.0, "device": 0.0, "writer": 0.0}     # where this thread sat still (logged at the end)
 
     def flush(keep=0):
@@ -327,6 +328,7 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
         flag_pins = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(NSLOT)]
         slot_done = [None] * NSLOT
     turn = 0
+    t_loop0 = time.perf_counter()
     try:
         while True:
             t0 = time.perf_counter()
@@ -410,10 +412,12 @@ def run_native(trainer, rspecifier, writer, min_chunk_size, chunk_size, normaliz
         wthread.join()
     if werr:
         raise werr[0]
-    log.info("[INFO] driver loop: %d batches; waited %.3f s for the reader, %.3f s for the device, %.3f s for the writer"
-             % (turn, waited["reader"], waited["device"], waited["writer"]))
+    log.info("[INFO] driver loop: %d batches; waited %.3f s for the reader, %.3f s for the device, %.3f s for the writer; "
+             "set-up (staging buffers, reader, threads) %.3f s, loop %.3f s"
+             % (turn, waited["reader"], waited["device"], waited["writer"], t_loop0 - t_enter, time.perf_counter() - t_loop0))
     skipped = reader.skipped + extra_skipped
-    reader.close()
+    # (closing unmaps the input -- gigabytes of page cache for a large ark, ~0.1 s -- : beside the caller's own teardown)
+    threading.Thread(target=reader.close, daemon=True).start()
     return done, skipped
 
 
@@ -476,8 +480,9 @@ def main(argv=None):
             min_chunk_size=args.min_chunk_size, chunk_size=args.chunk_size, normalize=args.normalize,
             batch_frames=args.batch_frames)
     rc = writer.close()
+    elapsed = time.perf_counter() - t_loop          # read - embed - write incl. the output flush; not the teardown below
     trainer.close()
-    log.info("Extracted %d embeddings (%d utterances skipped) in %.3f s" % (done, skipped, time.perf_counter() - t_loop))
+    log.info("Extracted %d embeddings (%d utterances skipped) in %.3f s" % (done, skipped, elapsed))
     if rc != 0:
         log.error("the output command of %s exited with code %d" % (args.wspecifier, rc))
         return 1
