@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""Where a job's start-up goes (fresh process): imports, first touch of the GPU, graph build, weight upload, pinned staging
+buffers, first forward (tiny batch, full batch) and a steady one.  usage: python tools/startup_probe.py"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 t0 = time.perf_counter()
