@@ -32,7 +32,8 @@ def default_precision(network_type):
     both poolings, ragged batches, the rescaled-layer and feature-range tests), with both ends of the fp16 range guarded (values
     beyond +-65504 and feature batches below 2^-8 never produce wrong vectors: Trainer and the command-line driver run such a batch again in bf16x3).  Its two-unit
     kernel covers the 5 / 7 / 9-tap convolutions of the (extended) TDNN and the stride-1 3 x 3 convolutions of the ResNet stages of
-    128 channels and more; "bf16x3" (full fp32 exponent range, no such refusals) stays one argument away."""
+    128 channels and more; "bf16x3" (full fp32 exponent range, no such refusals) stays one argument away -- and is what a defaulted
+    Trainer uses for a model none of whose layers the two-unit kernel applies to (channel counts not multiples of 128)."""
     return "f16f6" if network_type in ("tdnn", "extended_tdnn", "resnet_18") else DEFAULT_PRECISION
 
 
@@ -74,6 +75,7 @@ class Trainer(object):
         self.first_feature_split_alert = True
         self.embeddings = None            # name of the endpoint predict() returns
         self._precision = precision or os.environ.get("XVEC_PRECISION") or default_precision(params.network_type)
+        self._precision_defaulted = not (precision or os.environ.get("XVEC_PRECISION"))
         if self._precision not in _PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_PRECISIONS))
         # The reference (fp32 TensorFlow) accepts any finite features.  The fp16 precisions refuse batches outside their range; with
@@ -209,6 +211,14 @@ class Trainer(object):
         else:
             scope = "etdnn" if self.params.network_type == "extended_tdnn" else "tdnn"
             k1 = np.asarray(weights[scope + "/tdnn1_conv/kernel"])
+        # A defaulted f16f6 only pays where its two-unit kernel runs: layers whose channel counts are multiples of 128 (the kernel
+        # takes channel blocks in quads).  A narrower model would get the f16x3 kernels -- the fp16 range limits for nothing -- so
+        # it runs in bf16x3 instead.  (ResNet stage widths are w, 2w, 4w, 8w.)
+        if self._precision_defaulted and self._precision == "f16f6":
+            widest = int(k1.shape[-1]) * (8 if self.params.network_type == "resnet_18" else 1)
+            if widest % 128 != 0:
+                self._precision = DEFAULT_PRECISION
+                self._range_fallback = False
         desc = self._make_desc(channels=k1.shape[-1])
         h = C.c_void_p()
         _lib.check(self._lib.xv_create(C.byref(desc), self._device_index, C.byref(h)))
